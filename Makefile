@@ -1,0 +1,28 @@
+# Builds libwrs_mi355x.so (gfx950 only) in-tree: whisper_rs_amd/libwrs_mi355x.so
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := whisper_rs_amd/csrc
+OBJDIR := build/obj
+SRCS := $(CSRC)/common.cpp $(CSRC)/gemm.hip $(CSRC)/elementwise.hip $(CSRC)/attention.hip $(CSRC)/logits.hip \
+        $(CSRC)/mel.cpp $(CSRC)/model.cpp $(CSRC)/decode.cpp $(CSRC)/transcribe.cpp $(CSRC)/capi.cpp
+OBJS := $(patsubst $(CSRC)/%,$(OBJDIR)/%.o,$(SRCS))
+HDRS := $(wildcard $(CSRC)/*.h) include/wrs.h
+CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-unused-variable
+LIB := whisper_rs_amd/libwrs_mi355x.so
+
+all: $(LIB) examples/transcribe
+
+$(OBJDIR)/%.o: $(CSRC)/% $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+examples/transcribe: examples/transcribe.cpp $(LIB) include/wrs.h
+	g++ -O2 -std=c++17 -Iinclude -o $@ examples/transcribe.cpp -Lwhisper_rs_amd -lwrs_mi355x -Wl,-rpath,'$$ORIGIN/../whisper_rs_amd'
+
+clean:
+	rm -rf build $(LIB) examples/transcribe
+
+.PHONY: all clean

@@ -1,0 +1,263 @@
+/*
+ * wrs.h — C-ABI of the MI355X-native Whisper hot path (libwrs_mi355x.so).
+ *
+ * Drop-in boundary for laptou/whisper-rs (reference, Rust).  In the reference every
+ * tensor op crosses Rust->C through `tch`/`torch-sys` (Cargo.toml:16); this library
+ * replaces that op layer one level coarser (mel / encoder / decoder step / filter+select /
+ * window decode / transcribe) so that a `whisper` crate keeping the reference's public
+ * signatures can bind it with `extern "C"` only — no tch types cross this boundary
+ * (INTEGRATION.md shows the Rust side).  Each entry cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a WRS_E* code otherwise; wrs_last_error() gives
+ *     the thread-local message (reference: anyhow::Result / panics; never unwinds here).
+ *   - plain pointers and sizes only.  Host pointers unless a parameter says "device".
+ *   - handles are used from one thread at a time (reference types are !Send: Rc/RefCell).
+ *   - a task holds a non-owning pointer to its model: the model must outlive its tasks
+ *     (reference: DecodeTask<'a> borrows &'a Whisper, decode/mod.rs:24-25).
+ *   - there is NO CPU fallback: every compute entry fails with WRS_ENODEVICE if no gfx950
+ *     device is present.
+ */
+#ifndef WRS_H
+#define WRS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WRS_OK 0
+#define WRS_EINVAL 1     /* bad argument / shape (reference: debug_assert!/expect panics) */
+#define WRS_ENODEVICE 2  /* no HIP device / wrong arch */
+#define WRS_EHIP 3       /* HIP runtime error */
+#define WRS_ESTATE 4     /* call sequence error (e.g. model not finalized, missing tensor) */
+#define WRS_EUNSUPPORTED 5
+
+/* audio constants — reference src/audio.rs:12-18 */
+#define WRS_SAMPLE_RATE 16000
+#define WRS_N_FFT 400
+#define WRS_N_MELS 80
+#define WRS_HOP_LENGTH 160
+#define WRS_CHUNK_LENGTH 30
+#define WRS_N_SAMPLES 480000
+#define WRS_N_FRAMES 3000
+
+const char* wrs_last_error(void);
+const char* wrs_version(void);
+/* number of usable gfx950 devices (0 if none); never fails. */
+int wrs_device_count(void);
+
+/* ---------------------------------------------------------------- model (src/model.rs) */
+
+/* reference `ModelDims` (model.rs:546-557), same field order */
+typedef struct wrs_model_dims {
+    int64_t n_vocab;
+    int64_t n_audio_ctxs;
+    int64_t n_audio_states;
+    int64_t n_audio_heads;
+    int64_t n_audio_layers;
+    int64_t n_text_ctxs;
+    int64_t n_text_states;
+    int64_t n_text_heads;
+    int64_t n_text_layers;
+} wrs_model_dims;
+
+typedef struct wrs_model wrs_model;
+
+#define WRS_F32 0
+#define WRS_F16 1
+#define WRS_MEM_HOST 0
+#define WRS_MEM_DEVICE 1
+
+/* `Whisper::new(vs.root(), dims)` (model.rs:560-584, examples/transcribe.rs:22-36). */
+int wrs_model_create(const wrs_model_dims* dims, int device_id, wrs_model** out);
+/* `vars.load("weights.ot")` (examples/transcribe.rs:37), one tensor at a time.  `name` is the
+ * VarStore path (= OpenAI state_dict key); shape must match.  Values are
+ * converted to fp16 for the MFMA path (LayerNorm/bias/positional tensors stay fp32). */
+int wrs_model_set_tensor(wrs_model* m, const char* name, int dtype, const int64_t* shape, int ndim,
+                         const void* data, int mem_kind);
+/* checks every tensor of the manifest is present and builds the fused/packed device layouts. */
+int wrs_model_finalize(wrs_model* m);
+/* `Whisper::device()` (model.rs:601-603): HIP device ordinal. */
+int wrs_model_device(const wrs_model* m);
+int wrs_model_get_dims(const wrs_model* m, wrs_model_dims* out);
+void wrs_model_destroy(wrs_model* m);
+
+/* `AudioEncoder::forward` (model.rs:417-441).  mel: [n_audio, 80, 3000] f32;
+ * out: [n_audio, n_audio_ctxs, n_audio_states] f32. */
+int wrs_encoder_forward(wrs_model* m, const float* mel, int n_audio, float* out);
+
+/* `TextDecoder::forward_ext(tokens, xa, offset)` (model.rs:490-522) on the model's own K/V cache
+ * (reference: the `Cached` cells inside the model, model.rs:37-98).
+ *   tokens: [n_batch, n_tokens] i64; offset: positional-embedding offset of tokens[:,0];
+ *   xa: [n_batch, n_audio_ctxs, n_text_states] f32, or NULL to reuse the cross-attention K/V
+ *       computed by the previous call (the reference recomputes them on every call, model.rs:79;
+ *       same values — SURVEY.md Q4);
+ *   logits: [n_batch, n_tokens, n_vocab] f32.
+ * New self-attention K/V are appended after the cached ones (Cached::forward, model.rs:83-87). */
+int wrs_decoder_forward(wrs_model* m, const int64_t* tokens, int n_batch, int n_tokens, const float* xa,
+                        int64_t offset, float* logits);
+/* `Whisper::update_cache(&sources_indices)` (model.rs:591-594 -> :53-62): row r of every K/V cache
+ * becomes row src[r]. */
+int wrs_model_update_cache(wrs_model* m, const int64_t* src, int n_batch);
+/* `Whisper::clear_cache()` (model.rs:596-599). */
+int wrs_model_clear_cache(wrs_model* m);
+
+/* ---------------------------------------------------------------- audio (src/audio.rs) */
+
+/* `audio::mel_filter()` (audio.rs:175-188): out[80*201] row-major f32. */
+int wrs_mel_filter(float* out);
+/* `audio::pad_or_trim(x, len)` (audio.rs:213-228) on the last dim of a [rows, n] f32 array. */
+int wrs_pad_or_trim(const float* x, int64_t rows, int64_t n, int64_t len, float* out);
+/* `audio::log_mel_spectrogram(audio, mel_filter)` (audio.rs:230-259) on device `device_id`.
+ *   audio: [n_batch, n_samples] f32 (each row an independent recording: its own global max,
+ *   SURVEY.md Q11); filter: [80*201] f32 or NULL for wrs_mel_filter();
+ *   out: [n_batch, 80, n_samples/160] f32.  mem_kind applies to audio and out. */
+int wrs_log_mel_spectrogram(int device_id, const float* audio, int64_t n_batch, int64_t n_samples,
+                            const float* filter, float* out, int mem_kind);
+
+/* ---------------------------------------------------------------- decode (src/decode/) */
+
+/* special ids of reference `Tokenizer` (tokenize.rs:113-131) */
+typedef struct wrs_token_ids {
+    int32_t eot, sot, translate, transcribe, startoflm, startofprev, no_speech, no_timestamps, ts_begin;
+    int32_t space; /* tokenizer.encode(" ")[0] (suppress_blanks.rs:22-28) */
+} wrs_token_ids;
+
+#define WRS_EXTRACT_GREEDY 0      /* TokenExtractMode::Greedy { group_sze } (extractor/mod.rs:12-16) */
+#define WRS_EXTRACT_BEAM_SEARCH 1 /* TokenExtractMode::BeamSearch { beam_size, patience } */
+
+/* reference `DecodeOptions` (decode/mod.rs:95-106); the prompt is set with wrs_decode_task_set_prompt */
+typedef struct wrs_decode_options {
+    int32_t sample_len;            /* <=0: None -> n_text_ctxs/2 (decode/mod.rs:129-131) */
+    int32_t extract_mode;          /* WRS_EXTRACT_* */
+    int32_t group_size;            /* beam_size, or Greedy group_sze */
+    float patience;                /* beam search only */
+    int32_t has_len_penalty;       /* Option<f64> */
+    double len_penalty;
+    int32_t has_max_initial_timestamp;
+    double max_initial_timestamp;
+    int32_t timestamps;
+    int32_t suppress_blank;
+    int32_t suppress_non_speech;
+    const int32_t* suppress_tokens; /* Option<Vec<u32>>; may be NULL */
+    int32_t n_suppress_tokens;
+    const int32_t* non_speech_tokens; /* Tokenizer::non_speech_tokens() (tokenize.rs:215-307) */
+    int32_t n_non_speech_tokens;
+    int32_t position_offset_quirk;  /* 1 = reference behaviour: decoder offset = loop index (decode/mod.rs:244) */
+    int32_t max_audio;              /* capacity: windows decoded per run() call (>=1) */
+} wrs_decode_options;
+
+/* reference `DecodeOutput` (decode/mod.rs:109-119); text is produced by the caller's tokenizer */
+typedef struct wrs_decode_output {
+    int64_t* tokens; /* library-owned, n_tokens ids */
+    int32_t n_tokens;
+    double avg_logprob;
+    double no_speech_prob;
+    double sum_logprob;
+    const float* audio_features_device; /* device pointer [n_audio_ctxs, n_audio_states] fp32, valid until the next run */
+} wrs_decode_output;
+
+typedef struct wrs_decode_result {
+    wrs_decode_output* outputs;
+    int32_t n_outputs;
+    int32_t n_steps; /* sampling steps taken */
+} wrs_decode_result;
+
+typedef struct wrs_decode_task wrs_decode_task;
+
+/* `DecodeTask::new(&model, tokenizer, options)` (decode/mod.rs:122-204) */
+int wrs_decode_task_create(wrs_model* m, const wrs_token_ids* ids, const wrs_decode_options* opt,
+                           wrs_decode_task** out);
+/* `DecodeTask::set_prompt(Option<&Tensor>)` (decode/mod.rs:206-218); n==0 or NULL => None */
+int wrs_decode_task_set_prompt(wrs_decode_task* t, const int64_t* prompt, int32_t n);
+/* `DecodeTask::run(&mel)` (decode/mod.rs:284-419).  mel: [n_audio, 80, 3000] f32 (the reference's
+ * public run() takes one window; run_inner is batch-general, :291-347).  mem_kind: where mel lives. */
+int wrs_decode_task_run(wrs_decode_task* t, const float* mel, int32_t n_audio, int mem_kind,
+                        wrs_decode_result* result);
+/* same, starting from encoder output [n_audio, n_audio_ctxs, n_state] f32 (run_inner after :296) */
+int wrs_decode_task_run_features(wrs_decode_task* t, const float* audio_features, int32_t n_audio, int mem_kind,
+                                 wrs_decode_result* result);
+/* same, starting from raw audio windows [n_audio, 480000] f32: mel (per-window max) + run. */
+int wrs_decode_task_run_audio(wrs_decode_task* t, const float* audio, int32_t n_audio, int mem_kind,
+                              wrs_decode_result* result);
+/* per-step trace of the last run (test aid): for step s, row r: chosen token, source row, sum_logprob. */
+int wrs_decode_task_trace(wrs_decode_task* t, int32_t* n_steps, int32_t* n_rows, const int32_t** tokens,
+                          const int32_t** sources, const float** sum_logprobs);
+void wrs_decode_result_free(wrs_decode_result* r);
+void wrs_decode_task_destroy(wrs_decode_task* t);
+
+/* the reference's internal plug points (decode/filter/mod.rs:12-14, decode/extractor/mod.rs:20-73),
+ * exposed so each can be checked against the oracle in isolation:
+ * fused SuppressBlank -> SuppressTokens -> TimestampTokens (decode/mod.rs:156-190) followed by the
+ * extractor's log_softmax + top-k (beam_search.rs:37,62-65) on device.
+ *   logits: [n_rows, n_vocab] f32 host; tokens: [n_rows, n_tokens] i64 host (history incl. prompt);
+ *   sample_begin: prompt length; k <= 8;
+ *   out_logprobs/out_ids: [n_rows, k]; out_filtered (optional): [n_rows, n_vocab] filtered logits. */
+int wrs_filter_topk(wrs_decode_task* t, const float* logits, const int64_t* tokens, int32_t n_rows,
+                    int32_t n_tokens, int32_t sample_begin, int32_t k, float* out_logprobs, int32_t* out_ids,
+                    float* out_filtered);
+
+/* ---------------------------------------------------------------- transcribe (src/transcribe.rs) */
+
+/* reference `TranscribePrompt` (transcribe.rs:25-29); Text(String) is tokenized by the caller */
+typedef struct wrs_transcribe_options {
+    wrs_decode_options decode;
+    const int64_t* prompt_tokens; /* Pretokenized(Vec<u32>) or NULL for None{..} */
+    int32_t n_prompt_tokens;
+    int32_t condition_on_prev_text; /* used when prompt_tokens == NULL */
+} wrs_transcribe_options;
+
+/* reference `TranscribeOutputSegment` (transcribe.rs:59-67), text left to the caller's tokenizer */
+typedef struct wrs_segment {
+    int64_t seek;
+    double start_time, end_time;
+    int64_t start_token, end_token;
+} wrs_segment;
+
+typedef struct wrs_transcribe_output {
+    int64_t* tokens;
+    int64_t n_tokens;
+    wrs_segment* segments;
+    int64_t n_segments;
+    /* per decoded window (test aid) */
+    int64_t* window_seek;
+    double* window_avg_logprob;
+    double* window_no_speech_prob;
+    int64_t n_windows;
+} wrs_transcribe_output;
+
+typedef struct wrs_transcribe_task wrs_transcribe_task;
+
+/* `TranscribeTask::new(&model, options)` (transcribe.rs:70-101) */
+int wrs_transcribe_task_create(wrs_model* m, const wrs_token_ids* ids, const wrs_transcribe_options* opt,
+                               wrs_transcribe_task** out);
+/* `TranscribeTask::run(&audio)` (transcribe.rs:103-243): the sequential long-form loop. audio [n] f32 host. */
+int wrs_transcribe_task_run(wrs_transcribe_task* t, const float* audio, int64_t n_samples, wrs_transcribe_output* out);
+/* fixed-stride variant (= the reference's `seek += N_FRAMES` branch with conditioning off,
+ * transcribe.rs:231): windows are independent, decoded `batch` at a time; this is what shards over GPUs. */
+int wrs_transcribe_task_run_chunked(wrs_transcribe_task* t, const float* audio, int64_t n_samples, int32_t batch,
+                                    wrs_transcribe_output* out);
+void wrs_transcribe_output_free(wrs_transcribe_output* o);
+void wrs_transcribe_task_destroy(wrs_transcribe_task* t);
+
+/* ---------------------------------------------------------------- measurement hooks */
+
+/* per-kernel device timing of the last wrs_decode_task_run* call, measured with HIP events on the
+ * library's own stream.  names[i] is a static string. Returns the number of entries written. */
+typedef struct wrs_stage_time {
+    const char* name;
+    double ms;          /* summed device time */
+    int64_t launches;
+    double bytes;       /* algorithmic bytes moved, summed over launches (0 if compute-bound) */
+    double flops;       /* algorithmic flops, summed over launches */
+} wrs_stage_time;
+int wrs_decode_task_set_profiling(wrs_decode_task* t, int enabled);
+int wrs_decode_task_stage_times(wrs_decode_task* t, wrs_stage_time* out, int32_t cap, int32_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WRS_H */

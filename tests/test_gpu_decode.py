@@ -1,0 +1,156 @@
+"""GPU parity: DecodeTask::run (reference src/decode/mod.rs:284-419) — encoder, sampling loop with the
+fused filters, beam search / greedy, ranking — vs the CPU oracle on identical seeded inputs.
+
+Bar: token ids and beam source indices bit-exact at every step; sum_logprobs within LP_TOL.
+fp16 activations perturb logits by ~1e-3 relative, so on synthetic (random-weight) models two beam
+candidates can be closer than that; when the traces split, the test requires the split to be such a
+near-tie (the per-audio sorted beam scores of both sides still agree within LP_TOL at the split step)
+and to come after MIN_EXACT_STEPS exact steps.  Anything else fails."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import gpu_model, oracle_model, oracle_ids, oracle_decode_options, mel_windows
+from whisper_rs_amd.consts import MODEL_DIMS, TokenIds
+from oracle import decode as OD
+
+pytestmark = pytest.mark.gpu
+LP_TOL = 5e-2       # absolute, on cumulative log-probs of magnitude ~1e1..1e3
+MIN_EXACT_STEPS = 6
+
+
+def _oracle_run(dims_name, mel, oopts, prompt=None, **wkw):
+    om = oracle_model(dims_name, **wkw)
+    task = OD.DecodeTask(om, oracle_ids(MODEL_DIMS[dims_name].n_vocab), oopts)
+    if prompt is not None:
+        task.set_prompt(torch.tensor(prompt, dtype=torch.int64))
+    outs = task.run_batch(torch.from_numpy(mel))
+    tr = task.extractor.trace
+    return outs, (np.stack([t[0].numpy() for t in tr]), np.stack([t[1].numpy() for t in tr]), np.stack([t[2].numpy() for t in tr]))
+
+
+def _compare(gouts, gtrace, oouts, otrace, group):
+    gt, gs, gl = gtrace
+    ot, os_, ol = otrace
+    n = min(gt.shape[0], ot.shape[0])
+    split = None
+    for s in range(n):
+        if not (np.array_equal(gt[s], ot[s]) and np.array_equal(gs[s], os_[s])):
+            split = s
+            break
+        assert np.abs(gl[s] - ol[s]).max() < LP_TOL, f"step {s}: sum_logprobs differ by {np.abs(gl[s] - ol[s]).max()}"
+    if split is None:
+        assert gt.shape[0] == ot.shape[0], f"step counts differ: {gt.shape[0]} vs {ot.shape[0]}"
+        for g, o in zip(gouts, oouts):
+            np.testing.assert_array_equal(g.tokens, o.tokens.numpy())
+            assert abs(g.sum_logprob - o.sum_logprob) < LP_TOL
+            assert abs(g.avg_logprob - o.avg_logprob) < LP_TOL / max(1, len(g.tokens))  + 1e-3
+            assert abs(g.no_speech_prob - o.no_speech_prob) < 1e-4 + 0.02 * o.no_speech_prob
+        return None
+    assert split >= MIN_EXACT_STEPS, f"traces split at step {split} (< {MIN_EXACT_STEPS}): not explainable by fp16 near-ties"
+    R = gt.shape[1]
+    for a in range(R // group):
+        sl = slice(a * group, (a + 1) * group)
+        d = np.abs(np.sort(gl[split][sl]) - np.sort(ol[split][sl])).max()
+        assert d < LP_TOL, f"split at step {split}, audio {a}: beam scores differ by {d}: a real divergence, not a near-tie"
+    return split
+
+
+@pytest.mark.parametrize("dims_name,n_audio,sample_len", [("nano", 1, 16), ("micro", 2, 24), ("micro", 3, 40)])
+def test_beam_search_decode_vs_oracle(gpu, dims_name, n_audio, sample_len):
+    mel = mel_windows(n_audio)
+    oouts, otrace = _oracle_run(dims_name, mel, oracle_decode_options(sample_len=sample_len, beam_size=5))
+    gm = gpu_model(gpu, dims_name)
+    task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=sample_len, max_audio=n_audio))
+    gouts = task.run(mel)
+    split = _compare(gouts, task.trace(), oouts, otrace, 5)
+    print(f"{dims_name} x{n_audio}: steps {task.n_steps}, split {split}")
+    # second run on the same task must reproduce itself exactly (cache/ancestry reset)
+    gouts2 = task.run(mel)
+    for a, b in zip(gouts, gouts2):
+        np.testing.assert_array_equal(a.tokens, b.tokens)
+        assert a.sum_logprob == b.sum_logprob
+    task.close()
+
+
+def test_greedy_equals_beam1(gpu):
+    """greedy (unreachable in the reference) == greedy.rs update + one EOT pad; token-equal to beam_size 1."""
+    mel = mel_windows(2)
+    gm = gpu_model(gpu, "micro")
+    tg = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=20, max_audio=2, token_extract_mode=gpu.TokenExtractMode.Greedy()))
+    tb = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=20, max_audio=2, token_extract_mode=gpu.TokenExtractMode.BeamSearch(1, 1.0)))
+    og, ob = tg.run(mel), tb.run(mel)
+    for a, b in zip(og, ob):
+        np.testing.assert_array_equal(a.tokens, b.tokens)
+        assert abs(a.sum_logprob - b.sum_logprob) < 1e-3
+    oouts, otrace = _oracle_run("micro", mel, oracle_decode_options(sample_len=20, beam_size=None))
+    _compare(og, tg.trace(), oouts, otrace, 1)
+    tg.close(); tb.close()
+
+
+def test_forced_eot_finishes_early(gpu):
+    """weights built so <|endoftext|> wins around position 10: exercises finished/patience bookkeeping
+    (beam_search.rs:88-146) and finalize (151-206)."""
+    kw = dict(force_eot_after=10)
+    mel = mel_windows(2)
+    oouts, otrace = _oracle_run("micro", mel, oracle_decode_options(sample_len=40, beam_size=5), **kw)
+    gm = gpu_model(gpu, "micro", **kw)
+    task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=40, max_audio=2))
+    gouts = task.run(mel)
+    assert otrace[0].shape[0] < 40, "fixture did not finish early in the oracle; adjust force_eot_after"
+    _compare(gouts, task.trace(), oouts, otrace, 5)
+    task.close()
+
+
+def test_prompt_conditioning_and_position_quirk(gpu):
+    """set_prompt ([startofprev, prompt.., sot], decode/mod.rs:46-92) + the reference's offset = loop index (Q2)."""
+    mel = mel_windows(1)
+    prompt = [50364, 1000, 2000, 50400, 50400, 777]
+    for quirk in (True, False):
+        oouts, otrace = _oracle_run("micro", mel, oracle_decode_options(sample_len=16, beam_size=5, position_offset_quirk=quirk), prompt=prompt)
+        gm = gpu_model(gpu, "micro")
+        task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=16, position_offset_quirk=quirk))
+        task.set_prompt(prompt)
+        gouts = task.run(mel[0])
+        _compare(gouts, task.trace(), oouts, otrace, 5)
+        task.close()
+
+
+def test_options_matrix(gpu):
+    mel = mel_windows(1)
+    gm = gpu_model(gpu, "nano")
+    for kw_g, kw_o in [
+        (dict(timestamps=False), dict(timestamps=False)),
+        (dict(suppress_non_speech=False, suppress_tokens=[11, 13, 50257]), dict(suppress_non_speech=False, suppress_tokens=[11, 13, 50257])),
+        (dict(len_penalty=1.0, max_initial_timestamp=None), dict(len_penalty=1.0, max_initial_timestamp=None)),
+        (dict(token_extract_mode=gpu.TokenExtractMode.BeamSearch(3, 2.0)), dict(beam_size=3, patience=2.0)),
+    ]:
+        oouts, otrace = _oracle_run("nano", mel, oracle_decode_options(sample_len=12, **kw_o))
+        task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=12, **kw_g))
+        gouts = task.run(mel)
+        _compare(gouts, task.trace(), oouts, otrace, kw_o.get("beam_size", 5))
+        task.close()
+
+
+def test_run_audio_matches_run_mel(gpu):
+    from whisper_rs_amd import synth
+    a = synth.make_audio(2, seed=1234)
+    gm = gpu_model(gpu, "nano")
+    task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=10, max_audio=2))
+    o1 = task.run_audio(a)
+    o2 = task.run(gpu.audio.log_mel_spectrogram(a))
+    for x, y in zip(o1, o2):
+        np.testing.assert_array_equal(x.tokens, y.tokens)
+    task.close()
+
+
+def test_capacity_and_errors(gpu):
+    gm = gpu_model(gpu, "nano")
+    task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=4, max_audio=1))
+    with pytest.raises(gpu.WrsError):
+        task.run(mel_windows(2))
+    with pytest.raises(gpu.WrsError):
+        task.set_prompt([60000])
+    task.close()
+    with pytest.raises(gpu.WrsError):
+        gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(token_extract_mode=gpu.TokenExtractMode.BeamSearch(9, 1.0)))

@@ -1,0 +1,48 @@
+"""GPU parity: TranscribeTask::run (reference src/transcribe.rs:103-243) vs the oracle loop."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import gpu_model, oracle_model, oracle_ids, oracle_decode_options
+from whisper_rs_amd import synth
+from whisper_rs_amd.consts import TokenIds
+from oracle import transcribe as OT
+
+pytestmark = pytest.mark.gpu
+
+
+def _segments_equal(gs, os_):
+    assert len(gs) == len(os_)
+    for g, o in zip(gs, os_):
+        assert (g.seek, g.start_token, g.end_token) == (o.seek, o.start_token, o.end_token)
+        assert abs(g.start_time - o.start_time) < 1e-9 and abs(g.end_time - o.end_time) < 1e-9
+
+
+@pytest.mark.parametrize("condition", [False, True])
+def test_transcribe_long_form(gpu, condition):
+    audio = synth.make_audio(1, seed=77, n_samples=16000 * 50)[0]  # 50 s -> at least 2 windows
+    om = oracle_model("nano")
+    ot = OT.TranscribeTask(om, oracle_ids(), oracle_decode_options(sample_len=10), None, condition)
+    want = ot.run(torch.from_numpy(audio))
+    gm = gpu_model(gpu, "nano")
+    gt = gpu.TranscribeTask(gm, gpu.TranscribeOptions(decode=gpu.DecodeOptions(sample_len=10),
+                                                      prompt=gpu.TranscribePrompt.None_(condition)))
+    got = gt.run(audio)
+    assert [w[0] for w in got.windows] == [w[0] for w in want.windows], "seek sequence differs"
+    np.testing.assert_array_equal(got.tokens, want.tokens.numpy())
+    _segments_equal(got.segments, want.segments)
+    gt.close()
+
+
+def test_transcribe_chunked_equals_independent_windows(gpu):
+    """fixed-stride sharding unit: chunked batch decode == windows decoded one by one."""
+    audio = synth.make_audio(1, seed=5, n_samples=16000 * 95)[0]
+    gm = gpu_model(gpu, "nano")
+    opts = gpu.TranscribeOptions(decode=gpu.DecodeOptions(sample_len=8, max_audio=4), prompt=gpu.TranscribePrompt.None_(False))
+    gt = gpu.TranscribeTask(gm, opts)
+    a = gt.run_chunked(audio, 4)
+    b = gt.run_chunked(audio, 1)
+    np.testing.assert_array_equal(a.tokens, b.tokens)
+    assert len(a.windows) == 4 and [w[0] for w in a.windows] == [0, 3000, 6000, 9000]
+    _segments_equal(a.segments, b.segments)
+    gt.close()

@@ -1,0 +1,355 @@
+// Attention kernels for gfx950 (CDNA4).  head_dim = 64 for every Whisper size.
+// Replaces reference model.rs:169-201 (view/permute, q.matmul(k), softmax, matmul(v)).
+//
+// Layout idea (MI355X-first, not a port of a warp-32 tiling): K and V of one (batch, head) are
+// stored pre-packed in MFMA operand order, so that
+//   * every wave-level load is 1 KiB contiguous (lane-linear 16 B) straight into VGPRs — no LDS,
+//     no swizzle, full 128-B lines from HBM (decode cross-attention streams 246 MB/audio/step at
+//     large-v2, the dominant HBM stream of the whole path);
+//   * S^T = K Q^T is computed with keys as MFMA rows, so the fp32 score registers of two 16-key
+//     tiles ARE the B-operand fragment of the P·V product after an in-register fp16 convert: no
+//     cross-lane movement, no LDS round trip for P.
+// Packed formats for Tp = round_up(T, 32) keys:
+//   Kp [Tp/16][2][64 lanes][8]: (kt, ks, l, j) = K[kt*16 + (l&15)][ks*32 + 8*(l>>4) + j]
+//   Vp [Tp/32][4][64 lanes][8]: (kb, dt, l, j) = V[kb*32 + kperm(l>>4, j)][dt*16 + (l&15)]
+//        kperm(q, j) = j < 4 ? 4q + j : 16 + 4q + (j - 4)
+// (the k-order inside the P·V MFMA is permuted to match the score-register order).
+#include "kernels.h"
+
+namespace wrs {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+size_t packed_kv_halfs_per_head(int T) { return (size_t)round_up(T, 32) * 64; }
+
+// ------------------------------------------------------------------------------------------ pack
+// grid (Tp/32, H, n_batch), 256 threads.  One block packs 32 keys of one head: K is a permuted
+// 16-byte-chunk copy, V needs a transpose through LDS.
+__global__ __launch_bounds__(256) void pack_kv_kernel(const half_t* __restrict__ src, int64_t ld, int64_t k_off,
+                                                      int64_t v_off, int T, int H, half_t* __restrict__ kp,
+                                                      half_t* __restrict__ vp) {
+    __shared__ _Float16 vt[32][64 + 8];
+    const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int Tp = (T + 31) / 32 * 32;
+    const int64_t head_base = ((int64_t)b * H + h) * (int64_t)Tp * 64;
+    // K: 2 key tiles x 2 ksteps x 64 lanes = 256 chunks of 16 B
+    {
+        const int l = tid & 63, f = tid >> 6;  // f = tile_in_block*2 + ks
+        const int kt = kb * 2 + (f >> 1), ks = f & 1;
+        const int key = kt * 16 + (l & 15);
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < T) v = *reinterpret_cast<const half8*>(src + ((int64_t)b * T + key) * ld + k_off + h * 64 + ks * 32 + 8 * (l >> 4));
+        *reinterpret_cast<half8*>(kp + head_base + ((int64_t)(kt * 2 + ks) * 64 + l) * 8) = v;
+    }
+    // V: stage [32 keys][64 dims] in LDS
+    {
+        const int key_l = tid >> 3, c = tid & 7;
+        const int key = kb * 32 + key_l;
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < T) v = *reinterpret_cast<const half8*>(src + ((int64_t)b * T + key) * ld + v_off + h * 64 + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vt[key_l][c * 8 + j] = v[j];
+    }
+    __syncthreads();
+    {
+        const int l = tid & 63, dt = tid >> 6;
+        const int q = l >> 4, d = dt * 16 + (l & 15);
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key_l = j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4);
+            v[j] = vt[key_l][d];
+        }
+        *reinterpret_cast<half8*>(vp + head_base + ((int64_t)(kb * 4 + dt) * 64 + l) * 8) = v;
+    }
+}
+
+void launch_pack_kv(const half_t* src, int64_t ld, int64_t k_off, int64_t v_off, int n_batch, int T, int H, half_t* kp,
+                    half_t* vp, hipStream_t s) {
+    WRS_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "pack_kv: alignment");
+    dim3 grid((unsigned)cdiv(T, 32), (unsigned)H, (unsigned)n_batch);
+    pack_kv_kernel<<<grid, 256, 0, s>>>(src, ld, k_off, v_off, T, H, kp, vp);
+}
+
+// ------------------------------------------------------------------------------------------ MFMA attention
+// One wave = 16 query columns.  SPLIT = false: the wave walks all key blocks (encoder; 4 waves of a
+// block take 4 consecutive query tiles).  SPLIT = true: the 4 waves of a block share ONE query
+// tile (the G beams of one audio) and each takes every 4th key block; partial (m, l, O) are merged
+// through LDS (flash-decoding inside the workgroup).
+struct AttnParams {
+    const half_t* q;
+    int64_t ldq;
+    const half_t* kp;
+    const half_t* vp;
+    int T, Tp, H;
+    int q_rows_per_batch;  // rows per batch item in q / out
+    int q_valid;           // SPLIT: number of valid query rows (G); else unused
+    half_t* out;
+    int64_t ldo;
+};
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int qcol = lane & 15, qg = lane >> 4;
+
+    int q0, n_valid;
+    if (SPLIT) {
+        q0 = 0;
+        n_valid = p.q_valid;
+    } else {
+        q0 = (blockIdx.x * 4 + wave) * 16;
+        n_valid = p.q_rows_per_batch - q0;
+        if (n_valid <= 0) return;  // whole wave out of range (no barriers in the non-split kernel)
+        if (n_valid > 16) n_valid = 16;
+    }
+    const int64_t qrow0 = (int64_t)b * p.q_rows_per_batch + q0;
+
+    // Q^T as B operand: lane holds Q[q0 + qcol][ks*32 + 8*qg .. +7]
+    half8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (qcol < n_valid) v = *reinterpret_cast<const half8*>(p.q + (qrow0 + qcol) * p.ldq + h * 64 + ks * 32 + 8 * qg);
+        qf[ks] = v;
+    }
+
+    const int64_t head_base = ((int64_t)b * p.H + h) * (int64_t)p.Tp * 64;
+    const half_t* kbase = p.kp + head_base + lane * 8;
+    const half_t* vbase = p.vp + head_base + lane * 8;
+    const int n_blocks = p.Tp / 32;
+    const int kb_begin = SPLIT ? wave : 0, kb_step = SPLIT ? 4 : 1;
+
+    floatx4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    half8 kf[4], vf[4];
+    if (kb_begin < n_blocks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kf[i] = *reinterpret_cast<const half8*>(kbase + ((int64_t)kb_begin * 4 + i) * 512);
+            vf[i] = *reinterpret_cast<const half8*>(vbase + ((int64_t)kb_begin * 4 + i) * 512);
+        }
+    }
+    for (int kb = kb_begin; kb < n_blocks; kb += kb_step) {
+        half8 kc[4], vc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kc[i] = kf[i];
+            vc[i] = vf[i];
+        }
+        const int nxt = kb + kb_step;
+        if (nxt < n_blocks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kf[i] = *reinterpret_cast<const half8*>(kbase + ((int64_t)nxt * 4 + i) * 512);
+                vf[i] = *reinterpret_cast<const half8*>(vbase + ((int64_t)nxt * 4 + i) * 512);
+            }
+        }
+        // S^T tiles: rows = keys, cols = queries.  kc[tile*2 + ks]
+        floatx4 s0 = floatx4{0.f, 0.f, 0.f, 0.f}, s1 = floatx4{0.f, 0.f, 0.f, 0.f};
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0], qf[0], s0, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1], qf[1], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[2], qf[0], s1, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[3], qf[1], s1, 0, 0, 0);
+        float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        if (kb * 32 + 32 > p.T) {  // tail block: mask padded keys
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = kb * 32 + (j < 4 ? 4 * qg + j : 16 + 4 * qg + (j - 4));
+                if (key >= p.T) sv[j] = -INFINITY;
+            }
+        }
+        float bm = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+        bm = fmaxf(bm, __shfl_xor(bm, 16));
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float m_new = fmaxf(m_run, bm);  // every block holds >= 1 valid key, so m_new is finite
+        const float alpha = __expf(m_run - m_new);
+        float ps = 0.f;
+        half8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float e = __expf(sv[j] - m_new);
+            ps += e;
+            pf[j] = (_Float16)e;
+        }
+        ps += __shfl_xor(ps, 16);
+        ps += __shfl_xor(ps, 32);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            o[dt] *= alpha;
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vc[dt], pf, o[dt], 0, 0, 0);
+        }
+    }
+
+    if (!SPLIT) {
+        if (qcol < n_valid) {
+            const float inv = 1.f / l_run;
+            half_t* dst = p.out + (qrow0 + qcol) * p.ldo + h * 64 + 4 * qg;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<half4*>(dst + dt * 16) = half4{(_Float16)(o[dt][0] * inv), (_Float16)(o[dt][1] * inv),
+                                                                 (_Float16)(o[dt][2] * inv), (_Float16)(o[dt][3] * inv)};
+        }
+        return;
+    } else {
+        __shared__ float sm[4][16];
+        __shared__ float sl[4][16];
+        __shared__ float so[4][64][17];
+        if (qg == 0) {
+            sm[wave][qcol] = m_run;
+            sl[wave][qcol] = l_run;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) so[wave][dt * 16 + 4 * qg + r][qcol] = o[dt][r];
+        __syncthreads();
+        // 16 queries x 64 dims = 1024 outputs, 4 consecutive dims per thread
+        const int qq = tid >> 4, d0 = (tid & 15) * 4;
+        if (qq < n_valid) {
+            float mm = fmaxf(fmaxf(sm[0][qq], sm[1][qq]), fmaxf(sm[2][qq], sm[3][qq]));
+            float wgt[4], lsum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                wgt[w] = __expf(sm[w][qq] - mm);  // waves that saw no key block hold m = -inf, l = 0 -> weight 0
+                lsum += wgt[w] * sl[w][qq];
+            }
+            const float inv = 1.f / lsum;
+            float r4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) a += wgt[w] * so[w][d0 + r][qq];
+                r4[r] = a * inv;
+            }
+            *reinterpret_cast<half4*>(p.out + (qrow0 + qq) * p.ldo + h * 64 + d0) =
+                half4{(_Float16)r4[0], (_Float16)r4[1], (_Float16)r4[2], (_Float16)r4[3]};
+        }
+    }
+}
+
+void launch_attn_full(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_batch, int Tq, int T, int H,
+                      half_t* out, int64_t ldo, hipStream_t s) {
+    WRS_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && T >= 1 && Tq >= 1, "attn_full: bad shape");
+    AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, Tq, 0, out, ldo};
+    dim3 grid((unsigned)cdiv(Tq, 64), (unsigned)H, (unsigned)n_batch);
+    attn_mfma_kernel<false><<<grid, 256, 0, s>>>(p);
+}
+
+void launch_attn_cross(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_audio, int G, int T, int H,
+                       half_t* out, int64_t ldo, hipStream_t s) {
+    WRS_REQUIRE(G >= 1 && G <= 16, "attn_cross: group size %d not in 1..16", G);
+    WRS_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && T >= 1, "attn_cross: bad shape");
+    AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, G, G, out, ldo};
+    dim3 grid(1, (unsigned)H, (unsigned)n_audio);
+    attn_mfma_kernel<true><<<grid, 256, 0, s>>>(p);
+}
+
+// ------------------------------------------------------------------------------------------ decode self-attention
+// One wave per (row, head); K/V rows come from the ancestry-indirected cache
+// kc/vc [phys_row][n_ctx][D].  Lanes = 8 position groups x 8 dim chunks (16 B each): every wave
+// load instruction fetches 8 full 128-B lines.  Length <= 448, so scores live in LDS.
+__global__ __launch_bounds__(256) void attn_self_kernel(const half_t* __restrict__ q, int64_t ldq,
+                                                        const half_t* __restrict__ kc, const half_t* __restrict__ vc,
+                                                        const int* __restrict__ anc_base, int64_t anc_buf_stride, int n_ctx,
+                                                        int n_rows, int phys_mul, int H, int D,
+                                                        const StepParams* __restrict__ sp, half_t* __restrict__ out,
+                                                        int64_t ldo) {
+    __shared__ float sc[4][512];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= n_rows * H) return;  // no block-level barriers below
+    const int row = unit / H, h = unit % H;
+    const int g = lane >> 3, c = lane & 7;
+    const int len = sp->cache_pos + 1;
+    const int phys = row * phys_mul;
+    const int* anc = anc_base + (int64_t)sp->parity * anc_buf_stride + (int64_t)phys * n_ctx;
+    const int64_t row_stride = (int64_t)n_ctx * D;
+
+    float qv[8];
+    {
+        const half8 t = *reinterpret_cast<const half8*>(q + (int64_t)row * ldq + h * 64 + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = (float)t[j];
+    }
+    float mx = -INFINITY;
+    for (int p0 = 0; p0 < len; p0 += 8) {
+        const int pos = p0 + g;
+        float s = -INFINITY;
+        if (pos < len) {
+            const int pr = anc[pos];
+            const half8 kv = *reinterpret_cast<const half8*>(kc + (int64_t)pr * row_stride + (int64_t)pos * D + h * 64 + c * 8);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += qv[j] * (float)kv[j];
+            s = a;
+        }
+        // reduce the 8 dim-chunk partials (lanes differing in bits 0..2)
+        float t = (pos < len) ? s : 0.f;
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        t += __shfl_xor(t, 4);
+        if (pos < len) {
+            if (c == 0) sc[wave][pos] = t;
+            mx = fmaxf(mx, t);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    float sum = 0.f;
+    for (int pos = lane; pos < len; pos += 64) {
+        const float e = __expf(sc[wave][pos] - mx);
+        sc[wave][pos] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const float inv = 1.f / sum;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < len; p0 += 8) {
+        const int pos = p0 + g;
+        if (pos < len) {
+            const int pr = anc[pos];
+            const float w = sc[wave][pos];
+            const half8 vv = *reinterpret_cast<const half8*>(vc + (int64_t)pr * row_stride + (int64_t)pos * D + h * 64 + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w * (float)vv[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc[j] += __shfl_xor(acc[j], 8);
+        acc[j] += __shfl_xor(acc[j], 16);
+        acc[j] += __shfl_xor(acc[j], 32);
+    }
+    if (g == 0) {
+        half8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (_Float16)(acc[j] * inv);
+        *reinterpret_cast<half8*>(out + (int64_t)row * ldo + h * 64 + c * 8) = r;
+    }
+}
+
+void launch_attn_self(const half_t* q, int64_t ldq, const half_t* kc, const half_t* vc, const int* anc_base,
+                      int64_t anc_buf_stride, int n_ctx, int n_rows, int phys_mul, int H, int D, const StepParams* sp,
+                      half_t* out, int64_t ldo, hipStream_t s) {
+    WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && ldq % 8 == 0 && ldo % 8 == 0, "attn_self: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
+    const unsigned grid = (unsigned)cdiv((int64_t)n_rows * H, 4);
+    attn_self_kernel<<<grid, 256, 0, s>>>(q, ldq, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, ldo);
+}
+
+}  // namespace wrs

@@ -1,0 +1,16 @@
+#include "common.h"
+namespace wrs {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& m) { g_last_error = m; }
+const std::string& last_error() { return g_last_error; }
+void require_device(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) WRS_THROW(WRS_ENODEVICE, "no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) WRS_THROW(WRS_ENODEVICE, "device %d out of range (%d devices)", device_id, n);
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        WRS_THROW(WRS_ENODEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+}
+}  // namespace wrs

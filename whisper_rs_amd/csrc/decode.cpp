@@ -1,0 +1,398 @@
+// Host sequencer of one window batch.  Restates reference src/decode/mod.rs (DecodeTask),
+// decode/extractor/{beam_search,greedy}.rs and decode/sequencer/max_likelihood.rs on top of the
+// device step (Model::decoder_step) and the fused filter/top-k kernel.  The device produces
+// (beam+1) (logprob, id) pairs per row per step in pinned memory; everything the reference does
+// with HashMaps on the host stays on the host, made deterministic:
+//   candidates keep first-insertion order, duplicates overwrite (score, source) in place
+//   (beam_search.rs:77), stable sort by score descending (:86), newly finished sequences are
+//   admitted in that order (:131-137), final candidates are listed in admission order.
+#include "decode.h"
+#include <algorithm>
+#include <cmath>
+
+namespace wrs {
+
+static double round_half_away(double x) { return x >= 0 ? std::floor(x + 0.5) : -std::floor(-x + 0.5); }
+
+DecodeTask::~DecodeTask() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+}
+
+void DecodeTask::configure(Model* model, const wrs_token_ids& tid, const wrs_decode_options& o) {
+    WRS_REQUIRE(model && model->finalized, "DecodeTask: model is not finalized");
+    m = model;
+    ids = tid;
+    const int V = m->V;
+    WRS_REQUIRE(ids.eot >= 0 && ids.eot < V && ids.sot >= 0 && ids.sot < V && ids.ts_begin > 0 && ids.ts_begin <= V &&
+                    ids.no_speech >= 0 && ids.no_speech < V && ids.no_timestamps >= 0 && ids.no_timestamps < V &&
+                    ids.startofprev >= 0 && ids.startofprev < V && ids.space >= 0 && ids.space < V,
+                "DecodeTask: special token ids out of range for n_vocab %d", V);
+    sample_len = o.sample_len > 0 ? o.sample_len : m->n_ctx / 2;  // decode/mod.rs:129-131
+    mode = o.extract_mode;
+    WRS_REQUIRE(mode == WRS_EXTRACT_GREEDY || mode == WRS_EXTRACT_BEAM_SEARCH, "DecodeTask: unknown extract mode %d", mode);
+    group = o.group_size;
+    WRS_REQUIRE(group >= 1 && group <= 7, "DecodeTask: group/beam size %d not in 1..7", group);
+    patience = o.patience;
+    if (mode == WRS_EXTRACT_BEAM_SEARCH) WRS_REQUIRE(patience > 0, "DecodeTask: patience must be > 0");
+    has_len_penalty = o.has_len_penalty != 0;
+    len_penalty = o.len_penalty;
+    timestamps = o.timestamps != 0;
+    suppress_blank = o.suppress_blank != 0;
+    position_quirk = o.position_offset_quirk != 0;
+    max_audio = o.max_audio > 0 ? o.max_audio : 1;
+    mit = -1;
+    if (timestamps && o.has_max_initial_timestamp) {  // decode/mod.rs:176-183
+        const double precision = (double)WRS_CHUNK_LENGTH / (double)m->T;
+        mit = (int)round_half_away(o.max_initial_timestamp / precision);
+    }
+    suppress_ids.clear();
+    if ((o.suppress_tokens && o.n_suppress_tokens > 0) || o.suppress_non_speech) {  // decode/mod.rs:166-174
+        for (int i = 0; i < o.n_suppress_tokens; ++i) suppress_ids.push_back(o.suppress_tokens[i]);
+        if (o.suppress_non_speech) {
+            WRS_REQUIRE(o.non_speech_tokens || o.n_non_speech_tokens == 0, "DecodeTask: suppress_non_speech without a token list");
+            for (int i = 0; i < o.n_non_speech_tokens; ++i) suppress_ids.push_back(o.non_speech_tokens[i]);
+        }
+    }
+    for (int id : suppress_ids) WRS_REQUIRE(id >= 0 && id < V, "DecodeTask: suppress id %d out of range", id);
+    m->use();
+    suppress_dev.alloc(std::max<size_t>(suppress_ids.size(), 1) * 4);
+    if (!suppress_ids.empty())
+        HIP_CHECK(hipMemcpy(suppress_dev.p, suppress_ids.data(), suppress_ids.size() * 4, hipMemcpyHostToDevice));
+    m->init_state(st, max_audio, group);
+    set_prompt(nullptr, 0);
+    const char* env = getenv("WRS_NO_GRAPH");
+    use_graph = !(env && env[0] == '1');
+}
+
+void DecodeTask::set_prompt(const int64_t* p, int n) {  // decode/mod.rs:46-92,206-218
+    initial_tokens.clear();
+    if (p && n > 0) {
+        initial_tokens.push_back(ids.startofprev);
+        for (int i = 0; i < n; ++i) {
+            WRS_REQUIRE(p[i] >= 0 && p[i] < m->V, "set_prompt: token %ld out of range", (long)p[i]);
+            initial_tokens.push_back(p[i]);
+        }
+    }
+    initial_tokens.push_back(ids.sot);  // sequence_sot() == [sot] (tokenize.rs:201-205)
+    sample_begin = (int)initial_tokens.size();
+    sot_idx = 0;
+    for (size_t i = 0; i < initial_tokens.size(); ++i)
+        if (initial_tokens[i] == ids.sot) { sot_idx = (int)i; break; }
+}
+
+FilterCfg DecodeTask::filter_cfg() const {
+    FilterCfg c;
+    c.n_vocab = m->V;
+    c.ts_begin = ids.ts_begin; c.eot = ids.eot; c.no_timestamps = ids.no_timestamps; c.no_speech = ids.no_speech;
+    c.space = ids.space;
+    c.suppress_blank = suppress_blank ? 1 : 0;
+    c.timestamps = timestamps ? 1 : 0;
+    c.max_initial_ts_index = mit;
+    c.suppress_ids = suppress_dev.as<int>();
+    c.n_suppress = (int)suppress_ids.size();
+    return c;
+}
+
+void DecodeTask::upload_step(int) {
+    HIP_CHECK(hipMemcpyAsync(st.sp_dev.p, st.sp_host.p, st.sp_bytes(), hipMemcpyHostToDevice, m->stream));
+}
+
+static int ts_mode_of(const std::vector<int64_t>& row, int sample_begin, int tsb) {
+    // timestamp_tokens.rs:47-66
+    const int n = (int)row.size() - sample_begin;
+    const bool last = n >= 1 && row[row.size() - 1] >= tsb;
+    const bool second = n < 2 || row[row.size() - 2] >= tsb;
+    return last ? (second ? 1 : 2) : 0;
+}
+
+void DecodeTask::step_decode(int R) {
+    const int k = (mode == WRS_EXTRACT_BEAM_SEARCH) ? group + 1 : 1;
+    const FilterCfg cfg = filter_cfg();
+    auto body = [&]() {
+        upload_step(R);
+        m->decoder_step(st, R, 1, group, true, true);
+        launch_filter_topk(st.logits.as<float>(), R, cfg, st.sp_d(), st.tsmode_d(), k, st.topk_lp_d(), st.topk_id_d(),
+                           st.no_speech_d(), nullptr, m->stream);
+    };
+    const bool profiling = m->timer && m->timer->enabled;
+    if (use_graph && !profiling) {
+        if (!graph_exec || graph_rows != R) {
+            if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+            if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+            HIP_CHECK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+            try {
+                body();
+            } catch (...) {
+                hipGraph_t g = nullptr;
+                (void)hipStreamEndCapture(m->stream, &g);
+                if (g) (void)hipGraphDestroy(g);
+                throw;
+            }
+            HIP_CHECK(hipStreamEndCapture(m->stream, &graph));
+            HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+            graph_rows = R;
+        }
+        HIP_CHECK(hipGraphLaunch(graph_exec, m->stream));
+    } else {
+        body();
+    }
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+}
+
+void DecodeTask::record_trace(int R) {
+    for (int r = 0; r < R; ++r) {
+        tr_tokens.push_back((int32_t)rows[r].back());
+        tr_src.push_back(sources[r]);
+        tr_slp.push_back(sum_logprobs[r]);
+    }
+}
+
+// BeamSearchTokenExtractor::update (beam_search.rs:22-149).  step0: every beam of an audio reads the
+// audio's single prefill row (identical logits for identical rows; the reference computes them 5x).
+bool DecodeTask::update_beam(int n_audio, bool step0) {
+    const int G = group, k = G + 1;
+    const float* lp = st.topk_lp();
+    const int* id = st.topk_id();
+    struct Cand { int beam; int64_t token; double score; int source; };
+    std::vector<std::vector<int64_t>> new_rows((size_t)n_audio * G);
+    std::vector<float> new_slp((size_t)n_audio * G, 0.f);
+    std::vector<int> new_src((size_t)n_audio * G, 0);
+    const int max_candidates = (int)round_half_away((double)(patience * (float)G));  // :122
+    bool completed = true;
+    for (int i = 0; i < n_audio; ++i) {
+        std::vector<Cand> cands;
+        cands.reserve((size_t)G * k);
+        for (int j = 0; j < G; ++j) {
+            const int idx = i * G + j;
+            const int trow = step0 ? i : idx;
+            for (int c = 0; c < k; ++c) {
+                const int tok = id[trow * k + c];
+                if (tok < 0) continue;
+                const double score = (double)sum_logprobs[idx] + (double)lp[trow * k + c];  // :71
+                bool dup = false;
+                for (auto& e : cands) {
+                    if (e.token == tok && (e.beam == j || rows[i * G + e.beam] == rows[idx])) {
+                        e.score = score;  // HashMap insert overwrites the value, key position unchanged (:77)
+                        e.source = idx;
+                        dup = true;
+                        break;
+                    }
+                }
+                if (!dup) cands.push_back({j, tok, score, idx});
+            }
+        }
+        std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.score > b.score; });  // :86
+        std::vector<FinishedSeq> newly;
+        int saved = 0;
+        for (const auto& c : cands) {  // :87-104
+            if (c.token == ids.eot) {
+                FinishedSeq f;
+                f.tokens = rows[i * G + c.beam];
+                f.tokens.push_back(c.token);
+                f.score = c.score;
+                newly.push_back(std::move(f));
+            } else {
+                const int dst = i * G + saved;
+                new_rows[dst] = rows[i * G + c.beam];
+                new_rows[dst].push_back(c.token);
+                new_slp[dst] = (float)c.score;  // :91-95 stored into the f32 tensor
+                new_src[dst] = c.source;
+                if (++saved == G) break;
+            }
+        }
+        WRS_REQUIRE(saved == G, "beam search: only %d live candidates for audio %d (logits degenerate?)", saved, i);
+        auto& prev = finished[i];
+        for (auto& f : newly) {  // :124-138
+            if ((int)prev.size() >= max_candidates) break;
+            bool found = false;
+            for (auto& e : prev)
+                if (e.tokens == f.tokens) { e.score = f.score; found = true; break; }
+            if (!found) prev.push_back(std::move(f));
+        }
+        if ((int)prev.size() < max_candidates) completed = false;  // :141-146
+    }
+    rows.swap(new_rows);
+    sum_logprobs.swap(new_slp);
+    sources.swap(new_src);
+    return completed;
+}
+
+// GreedyTokenExtractor::update (greedy.rs:17-51), temperature 0.  completed = every row's last
+// token is EOT (OpenAI); the literal `tokens.eq(eot).all()` can never hold and the
+// outputs are identical either way because finished rows keep emitting EOT with no logprob added.
+bool DecodeTask::update_greedy(int n_audio, bool step0) {
+    const int G = group;
+    const float* lp = st.topk_lp();
+    const int* id = st.topk_id();
+    bool completed = true;
+    for (int r = 0; r < n_audio * G; ++r) {
+        const int trow = step0 ? r / G : r;
+        int64_t tok = id[trow];
+        WRS_REQUIRE(tok >= 0, "greedy: no finite logit in row %d", r);
+        const bool last_eot = rows[r].back() == ids.eot;
+        if (!last_eot) sum_logprobs[r] = sum_logprobs[r] + lp[trow];  // :38 (f32 add)
+        else tok = ids.eot;                                           // :40-44
+        rows[r].push_back(tok);
+        sources[r] = r;
+        if (tok != ids.eot) completed = false;
+    }
+    return completed;
+}
+
+void DecodeTask::run_loaded(int n_audio, wrs_decode_result* out) {
+    WRS_REQUIRE(n_audio >= 1 && n_audio <= max_audio, "run: %d windows exceed the task capacity %d", n_audio, max_audio);
+    m->use();
+    m->encoder_from_mel_t(n_audio);  // decode/mod.rs:296
+    run_encoded(n_audio, out);
+}
+
+void DecodeTask::run_encoded(int n_audio, wrs_decode_result* out) {
+    WRS_REQUIRE(out, "run: null result");
+    WRS_REQUIRE(n_audio >= 1 && n_audio <= max_audio, "run: %d windows exceed the task capacity %d", n_audio, max_audio);
+    m->use();
+    memset(out, 0, sizeof(*out));
+    const int G = group, R = n_audio * G, S = sample_begin;
+    WRS_REQUIRE(S <= m->n_ctx, "prompt of %d tokens exceeds n_text_ctxs %d (the reference panics slicing positional_embedding)", S, m->n_ctx);
+    hipStream_t s = m->stream;
+
+    m->load_cross_kv(st, m->enc_ws.xa16.as<half_t>(), n_audio);
+    launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m->n_ctx, m->n_ctx, st.r_cap, G, s);
+
+    // host state (decode/mod.rs:297-325)
+    rows.assign(R, initial_tokens);
+    sum_logprobs.assign(R, 0.f);
+    sources.assign(R, 0);
+    finished.assign(n_audio, {});
+    no_speech.assign(n_audio, NAN);
+    tr_tokens.clear(); tr_src.clear(); tr_slp.clear();
+    tr_rows = R;
+    n_steps = 0;
+
+    const int k = (mode == WRS_EXTRACT_BEAM_SEARCH) ? G + 1 : 1;
+    const FilterCfg cfg = filter_cfg();
+
+    // ---- forward pass i = 0 (decode/mod.rs:234-245): the S prompt tokens, one cache position at a time,
+    // on ONE row per audio (all beams of an audio are identical until the first selection).
+    for (int p = 0; p < S; ++p) {
+        StepParams* sp = st.sp_h();
+        sp->cache_pos = p; sp->pos_idx = p; sp->parity = 0; sp->first_step = 1;
+        sp->want_no_speech = (p == sot_idx) ? 1 : 0; sp->n_rows = n_audio;
+        for (int a = 0; a < n_audio; ++a) { st.tokens_h()[a] = (int)initial_tokens[p]; st.src_h()[a] = a; st.tsmode_h()[a] = 0; }
+        upload_step(n_audio);
+        const bool last = (p == S - 1);
+        const bool want_logits = last || p == sot_idx;
+        m->decoder_step(st, n_audio, G, 1, false, want_logits);
+        if (want_logits) {
+            launch_filter_topk(st.logits.as<float>(), n_audio, cfg, st.sp_d(), st.tsmode_d(), k, st.topk_lp_d(), st.topk_id_d(),
+                               st.no_speech_d(), nullptr, s);
+            HIP_CHECK(hipStreamSynchronize(s));
+            if (p == sot_idx)
+                for (int a = 0; a < n_audio; ++a) no_speech[a] = (double)st.no_speech_h()[a];  // decode/mod.rs:250-255
+        }
+    }
+    if (m->timer && m->timer->enabled) { HIP_CHECK(hipStreamSynchronize(s)); m->timer->collect(); }
+
+    bool completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, true) : update_greedy(n_audio, true);
+    record_trace(R);
+    n_steps = 1;
+
+    for (int i = 1; i < sample_len; ++i) {  // decode/mod.rs:234-277
+        if (completed || (int)rows[0].size() > m->n_ctx) break;
+        StepParams* sp = st.sp_h();
+        sp->cache_pos = S + i - 1;
+        sp->pos_idx = position_quirk ? i : S + i - 1;
+        WRS_REQUIRE(sp->pos_idx < m->n_ctx && sp->cache_pos < m->n_ctx, "decode: position %d out of range", sp->cache_pos);
+        sp->parity = i & 1; sp->first_step = 0; sp->want_no_speech = 0; sp->n_rows = R;
+        for (int r = 0; r < R; ++r) {
+            st.tokens_h()[r] = (int)rows[r].back();
+            st.src_h()[r] = sources[r];
+            st.tsmode_h()[r] = timestamps ? ts_mode_of(rows[r], S, ids.ts_begin) : 0;
+        }
+        step_decode(R);
+        if (m->timer && m->timer->enabled) m->timer->collect();
+        completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, false) : update_greedy(n_audio, false);
+        record_trace(R);
+        n_steps = i + 1;
+    }
+    finalize(n_audio, out);
+    out->n_steps = n_steps;
+}
+
+// finalize (beam_search.rs:151-206 / greedy.rs:54-58), slice [sample_begin, first EOT) (decode/mod.rs:356-370),
+// MaximumLikelihoodRanker::rank (max_likelihood.rs:13-34), avg_logprob (decode/mod.rs:389-397).
+void DecodeTask::finalize(int n_audio, wrs_decode_result* out) {
+    const int G = group;
+    std::vector<std::vector<FinishedSeq>> cands(n_audio);
+    for (int i = 0; i < n_audio; ++i) {
+        if (mode == WRS_EXTRACT_BEAM_SEARCH) {
+            auto& seqs = finished[i];
+            if ((int)seqs.size() < G) {
+                std::vector<int> order(G);
+                for (int j = 0; j < G; ++j) order[j] = j;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sum_logprobs[i * G + a] < sum_logprobs[i * G + b]; });
+                for (int t = G - 1; t >= 0; --t) {
+                    const int j = order[t];
+                    FinishedSeq f;
+                    f.tokens = rows[i * G + j];
+                    f.tokens.push_back(ids.eot);
+                    f.score = (double)sum_logprobs[i * G + j];
+                    bool found = false;
+                    for (auto& e : seqs)
+                        if (e.tokens == f.tokens) { e.score = f.score; found = true; break; }
+                    if (!found) seqs.push_back(std::move(f));
+                    if ((int)seqs.size() >= G) break;
+                }
+            }
+            cands[i] = seqs;
+        } else {
+            for (int j = 0; j < G; ++j) {
+                FinishedSeq f;
+                f.tokens = rows[i * G + j];
+                f.tokens.push_back(ids.eot);
+                f.score = (double)sum_logprobs[i * G + j];
+                cands[i].push_back(std::move(f));
+            }
+        }
+    }
+    out->outputs = (wrs_decode_output*)calloc(n_audio, sizeof(wrs_decode_output));
+    out->n_outputs = n_audio;
+    for (int i = 0; i < n_audio; ++i) {
+        int best = 0;
+        double best_score = -INFINITY;
+        bool have = false;
+        std::vector<std::pair<int, int>> spans(cands[i].size());
+        for (size_t c = 0; c < cands[i].size(); ++c) {
+            const auto& t = cands[i][c].tokens;
+            int end = (int)t.size();
+            for (int q = 0; q < (int)t.size(); ++q)
+                if (t[q] == ids.eot) { end = q; break; }
+            const int begin = std::min(sample_begin, end);
+            spans[c] = {begin, end};
+            const double length = (double)(end - begin);
+            const double penalty = has_len_penalty ? std::pow((5.0 + length) / 6.0, len_penalty) : length;
+            const double score = cands[i][c].score / penalty;
+            if (!have || score > best_score) { best = (int)c; best_score = score; have = true; }  // argmax: first maximum
+        }
+        const auto& t = cands[i][best].tokens;
+        const int begin = spans[best].first, end = spans[best].second;
+        wrs_decode_output& o = out->outputs[i];
+        o.n_tokens = end - begin;
+        o.tokens = (int64_t*)malloc(sizeof(int64_t) * std::max(1, o.n_tokens));
+        for (int q = begin; q < end; ++q) o.tokens[q - begin] = t[q];
+        o.sum_logprob = cands[i][best].score;
+        o.avg_logprob = cands[i][best].score / ((double)o.n_tokens + 1.0);
+        o.no_speech_prob = no_speech[i];
+        o.audio_features_device = m->enc_ws.xa32.as<float>() + (size_t)i * m->T * m->D;
+    }
+}
+
+void free_decode_result(wrs_decode_result* r) {
+    if (!r || !r->outputs) return;
+    for (int i = 0; i < r->n_outputs; ++i) free(r->outputs[i].tokens);
+    free(r->outputs);
+    r->outputs = nullptr;
+    r->n_outputs = 0;
+}
+
+}  // namespace wrs

@@ -1,0 +1,76 @@
+// DecodeTask: one <=30-s window batch: encoder -> sampling loop -> rank (reference src/decode/mod.rs).
+#pragma once
+#include "model.h"
+
+namespace wrs {
+
+struct FinishedSeq {
+    std::vector<int64_t> tokens;
+    double score;
+};
+
+struct DecodeTask {
+    Model* m = nullptr;
+    wrs_token_ids ids{};
+    // options (reference DecodeOptions, decode/mod.rs:95-106)
+    int sample_len = 0;
+    int mode = WRS_EXTRACT_BEAM_SEARCH;
+    int group = 5;
+    float patience = 1.f;
+    bool has_len_penalty = false;
+    double len_penalty = 0;
+    bool timestamps = true, suppress_blank = true;
+    int mit = -1;  // max_initial_timestamp_index, -1 = None
+    bool position_quirk = true;
+    int max_audio = 1;
+    std::vector<int> suppress_ids;
+    DevBuf suppress_dev;
+
+    // prompt (reference DecodePrompt, decode/mod.rs:46-92)
+    std::vector<int64_t> initial_tokens;
+    int sample_begin = 1, sot_idx = 0;
+
+    DecState st;
+    MelWorkspace mel_ws;
+    DevBuf audio_dev, mel_dev;
+
+    // host sequencer state
+    std::vector<std::vector<int64_t>> rows;  // [R] token history incl. prompt
+    std::vector<float> sum_logprobs;         // [R] (f32 like the reference's tensor)
+    std::vector<int> sources;                // [R]
+    std::vector<std::vector<FinishedSeq>> finished;  // per audio, admission order
+    std::vector<double> no_speech;
+    int n_steps = 0;
+
+    // trace (test aid)
+    std::vector<int32_t> tr_tokens, tr_src;
+    std::vector<float> tr_slp;
+    int tr_rows = 0;
+
+    // graph replay of the decode step
+    bool use_graph = true;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    int graph_rows = -1;
+
+    ~DecodeTask();
+    void configure(Model* model, const wrs_token_ids& ids, const wrs_decode_options& o);
+    void set_prompt(const int64_t* p, int n);
+    FilterCfg filter_cfg() const;
+
+    // window batch already loaded in m->enc_ws.mel_t
+    void run_loaded(int n_audio, wrs_decode_result* out);
+    // encoder output already in m->enc_ws.xa16/xa32
+    void run_encoded(int n_audio, wrs_decode_result* out);
+
+    void upload_step(int rows_n);
+    void step_decode(int rows_n);  // decoder_step + filter_topk for rows_n = n_audio*group rows (graph-replayed)
+    bool update_beam(int n_audio, bool step0);
+    bool update_greedy(int n_audio, bool step0);
+    void finalize(int n_audio, wrs_decode_result* out);
+    void record_trace(int R);
+};
+
+void free_decode_result(wrs_decode_result* r);
+
+}  // namespace wrs

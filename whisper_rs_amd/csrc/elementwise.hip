@@ -1,0 +1,304 @@
+// Memory-bound helper kernels (gfx950): mel pre/post-processing, LayerNorm (one 64-lane wave
+// per row, fp32 statistics), split-K finish + residual + LayerNorm fusion, embedding lookup,
+// beam-ancestry table maintenance.  All loads/stores are 16-byte vectors where the layout allows.
+#include "kernels.h"
+
+namespace wrs {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------ mel
+// reference audio.rs:236-246: stft(center=true, pad_mode="reflect") pads n_fft/2 = 200 samples each side.
+__global__ void reflect_pad_kernel(const float* __restrict__ audio, int64_t n, float* __restrict__ out, int64_t out_stride) {
+    const int64_t b = blockIdx.y;
+    const float* src = audio + b * n;
+    float* dst = out + b * out_stride;
+    const int64_t total = n + 400;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < out_stride; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < total) {
+            int64_t j = i - 200;
+            if (j < 0) j = -j;
+            else if (j >= n) j = 2 * (n - 1) - j;
+            v = src[j];
+        }
+        dst[i] = v;
+    }
+}
+void launch_reflect_pad(const float* audio, int64_t n_batch, int64_t n, float* out, int64_t out_stride, hipStream_t s) {
+    dim3 grid((unsigned)std::min<int64_t>(cdiv(out_stride, 256), 2048), (unsigned)n_batch);
+    reflect_pad_kernel<<<grid, 256, 0, s>>>(audio, n, out, out_stride);
+}
+
+__global__ void fill_f32_kernel(float* p, float v, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill_f32(float* p, float v, int64_t n, hipStream_t s) {
+    fill_f32_kernel<<<(int)std::min<int64_t>(cdiv(n, 256), 2048), 256, 0, s>>>(p, v, n);
+}
+
+__device__ __forceinline__ float key_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+// reference audio.rs:256-258: floor at (global max - 8), then (x + 4) / 4; output in the reference's [80, F] layout.
+// 32x32 LDS transpose tile: reads time-major rows (coalesced over mel bins), writes frame-contiguous rows.
+__global__ void mel_finalize_kernel(const float* __restrict__ logmel, const int* __restrict__ maxkey, int64_t n_frames,
+                                    float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int64_t b = blockIdx.z;
+    const int64_t f0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const float floor_v = key_to_float(maxkey[b]) - 8.0f;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t f = f0 + r;
+        const int c = c0 + tx;
+        float v = 0.f;
+        if (f < n_frames && c < 80) v = logmel[(b * n_frames + f) * 80 + c];
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r;
+        const int64_t f = f0 + tx;
+        if (f < n_frames && c < 80) {
+            const float v = fmaxf(tile[tx][r], floor_v);
+            out[(b * 80 + c) * n_frames + f] = (v + 4.0f) / 4.0f;
+        }
+    }
+}
+void launch_mel_finalize(const float* logmel, const float* maxbuf, int64_t n_batch, int64_t n_frames, float* out,
+                         hipStream_t s) {
+    dim3 grid((unsigned)cdiv(n_frames, 32), 3, (unsigned)n_batch);
+    mel_finalize_kernel<<<grid, 256, 0, s>>>(logmel, reinterpret_cast<const int*>(maxbuf), n_frames, out);
+}
+
+// reference transcribe.rs:152 + audio.rs:213-228 (pad_or_trim of mel[:, seek:]) fused with the layout change the
+// conv1 implicit GEMM wants: [3002, 80] fp16 time-major, rows 0 and 3001 zero (conv padding=1).
+__global__ void mel_prep_kernel(const float* __restrict__ mel, int64_t n_frames, int64_t mel_bs, int64_t seek,
+                                half_t* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int64_t b = blockIdx.z;
+    const int64_t t0 = (int64_t)blockIdx.x * 32;  // window-relative frame
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {  // r: mel bin within tile, tx: frame within tile
+        const int c = c0 + r;
+        const int64_t t = t0 + tx, f = seek + t;
+        float v = 0.f;
+        if (c < 80 && t < 3000 && f < n_frames) v = mel[b * mel_bs + (int64_t)c * n_frames + f];
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {  // r: frame within tile, tx: mel bin
+        const int64_t t = t0 + r;
+        const int c = c0 + tx;
+        if (t < 3000 && c < 80) out[(b * 3002 + t + 1) * 80 + c] = (_Float16)tile[tx][r];
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 160) {
+        const int which = threadIdx.x / 80, c = threadIdx.x % 80;
+        out[(b * 3002 + (which ? 3001 : 0)) * 80 + c] = (_Float16)0.f;
+    }
+}
+void launch_mel_prep(const float* mel, int64_t n_batch, int64_t n_frames, int64_t mel_batch_stride, int64_t seek,
+                     half_t* out, hipStream_t s) {
+    dim3 grid((unsigned)cdiv(3000, 32), 3, (unsigned)n_batch);
+    mel_prep_kernel<<<grid, 256, 0, s>>>(mel, n_frames, mel_batch_stride, seek, out);
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// tch nn::LayerNorm defaults (eps 1e-5, affine) — reference model.rs:255-259,305,310,315,439,518.
+// One wave per row; the row lives in registers (D <= 64*4*NV), two-pass mean / variance in fp32.
+template <int NV>  // float4 vectors per lane
+__device__ __forceinline__ void ln_row(floatx4 (&v)[NV], int D, int lane, const float* __restrict__ g,
+                                       const float* __restrict__ b, half_t* o16, float* o32) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = v[i][r] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const floatx4 gg = *reinterpret_cast<const floatx4*>(g + c);
+            const floatx4 bb = *reinterpret_cast<const floatx4*>(b + c);
+            floatx4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (v[i][r] - mean) * rstd * gg[r] + bb[r];
+            if (o16) *reinterpret_cast<half4*>(o16 + c) = half4{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+            if (o32) *reinterpret_cast<floatx4*>(o32 + c) = y;
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, int64_t M, int D,
+                                                        half_t* __restrict__ out16, float* __restrict__ out32) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    floatx4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < D ? *reinterpret_cast<const floatx4*>(x + row * D + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    ln_row<NV>(v, D, lane, g, b, out16 ? out16 + row * D : nullptr, out32 ? out32 + row * D : nullptr);
+}
+
+static int ln_nv(int D) {
+    WRS_REQUIRE(D % 4 == 0 && D <= 2048, "layernorm: D=%d unsupported", D);
+    return (int)cdiv(D, 256);
+}
+
+void launch_layernorm(const float* x, const float* g, const float* b, int64_t M, int D, half_t* out16, float* out32,
+                      hipStream_t s) {
+    const unsigned grid = (unsigned)cdiv(M, 4);
+    switch (ln_nv(D)) {
+        case 1: layernorm_kernel<1><<<grid, 256, 0, s>>>(x, g, b, M, D, out16, out32); break;
+        case 2: layernorm_kernel<2><<<grid, 256, 0, s>>>(x, g, b, M, D, out16, out32); break;
+        case 3: layernorm_kernel<3><<<grid, 256, 0, s>>>(x, g, b, M, D, out16, out32); break;
+        case 4: layernorm_kernel<4><<<grid, 256, 0, s>>>(x, g, b, M, D, out16, out32); break;
+        case 5: layernorm_kernel<5><<<grid, 256, 0, s>>>(x, g, b, M, D, out16, out32); break;
+        default: layernorm_kernel<8><<<grid, 256, 0, s>>>(x, g, b, M, D, out16, out32); break;
+    }
+}
+
+// decode step: x[m] += bias + sum_s slab[s][m] (fixed order => deterministic), then xn = LN(x).
+// Fuses the split-K reduction of the out-projection / MLP-2 GEMM, the residual add
+// (reference model.rs:302-318) and the next LayerNorm into one pass over [M, D].
+template <int NV>
+__global__ __launch_bounds__(256) void finish_residual_ln_kernel(float* __restrict__ x, const float* __restrict__ slab,
+                                                                 int ksplit, int m_pad, const float* __restrict__ bias,
+                                                                 const float* __restrict__ g, const float* __restrict__ b,
+                                                                 int M, int D, half_t* __restrict__ xn) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    floatx4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            floatx4 a = *reinterpret_cast<const floatx4*>(x + (int64_t)row * D + c);
+            floatx4 acc = *reinterpret_cast<const floatx4*>(slab + (int64_t)row * D + c);
+            for (int sidx = 1; sidx < ksplit; ++sidx)
+                acc += *reinterpret_cast<const floatx4*>(slab + ((int64_t)sidx * m_pad + row) * D + c);
+            if (bias) acc += *reinterpret_cast<const floatx4*>(bias + c);
+            a += acc;
+            *reinterpret_cast<floatx4*>(x + (int64_t)row * D + c) = a;
+            v[i] = a;
+        } else {
+            v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if (xn) ln_row<NV>(v, D, lane, g, b, xn + (int64_t)row * D, nullptr);
+}
+
+void launch_finish_residual_ln(float* x, const float* slab, int ksplit, int m_pad, const float* bias, const float* g,
+                               const float* b, int M, int D, half_t* xn, hipStream_t s) {
+    const unsigned grid = (unsigned)cdiv(M, 4);
+    switch (ln_nv(D)) {
+#define WRS_FIN(NV) case NV: finish_residual_ln_kernel<NV><<<grid, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn); break;
+        WRS_FIN(1) WRS_FIN(2) WRS_FIN(3) WRS_FIN(4) WRS_FIN(5)
+#undef WRS_FIN
+        default: finish_residual_ln_kernel<8><<<grid, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn); break;
+    }
+}
+
+// reference model.rs:503-506: token_emb(tokens) + position_emb[offset..]; fused with the first block's attn_ln.
+template <int NV>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const half_t* __restrict__ emb, const float* __restrict__ pos,
+                                                       const StepParams* __restrict__ sp, const int* __restrict__ tokens,
+                                                       const float* __restrict__ g, const float* __restrict__ b, int M,
+                                                       int D, float* __restrict__ x, half_t* __restrict__ xn) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int tok = tokens[row];
+    const int pidx = sp->pos_idx;
+    floatx4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const half4 e = *reinterpret_cast<const half4*>(emb + (int64_t)tok * D + c);
+            const floatx4 pp = *reinterpret_cast<const floatx4*>(pos + (int64_t)pidx * D + c);
+            floatx4 a = floatx4{(float)e[0], (float)e[1], (float)e[2], (float)e[3]} + pp;
+            *reinterpret_cast<floatx4*>(x + (int64_t)row * D + c) = a;
+            v[i] = a;
+        } else {
+            v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    ln_row<NV>(v, D, lane, g, b, xn + (int64_t)row * D, nullptr);
+}
+
+void launch_embed_ln(const half_t* emb, const float* pos, const StepParams* sp, const int* tokens, const float* g,
+                     const float* b, int M, int D, float* x, half_t* xn, hipStream_t s) {
+    const unsigned grid = (unsigned)cdiv(M, 4);
+    switch (ln_nv(D)) {
+#define WRS_EMB(NV) case NV: embed_ln_kernel<NV><<<grid, 256, 0, s>>>(emb, pos, sp, tokens, g, b, M, D, x, xn); break;
+        WRS_EMB(1) WRS_EMB(2) WRS_EMB(3) WRS_EMB(4) WRS_EMB(5)
+#undef WRS_EMB
+        default: embed_ln_kernel<8><<<grid, 256, 0, s>>>(emb, pos, sp, tokens, g, b, M, D, x, xn); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ beam ancestry
+// Replaces `Cached::update_cache` (reference model.rs:53-62: cache.index([src]) gathers every K/V
+// tensor of every block each step).  Instead of moving K/V, each row keeps, per cached position, the
+// physical row that holds it; a beam re-index only gathers this int table (448 ints per row).
+__global__ void anc_init_kernel(int* anc_base, int64_t buf_stride, int n_ctx, int n_phys_rows, int G) {
+    const int64_t total = (int64_t)n_phys_rows * n_ctx;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / n_ctx);
+        const int v = (r / G) * G;
+        anc_base[i] = v;
+        anc_base[buf_stride + i] = v;
+    }
+}
+void launch_anc_init(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_phys_rows, int G, hipStream_t s) {
+    const int64_t total = (int64_t)n_phys_rows * n_ctx;
+    anc_init_kernel<<<(int)std::min<int64_t>(cdiv(total, 256), 2048), 256, 0, s>>>(anc_base, anc_buf_stride, n_ctx, n_phys_rows, G);
+}
+
+__global__ void anc_update_kernel(int* anc_base, int64_t buf_stride, int n_ctx, int n_rows,
+                                  const StepParams* __restrict__ sp, const int* __restrict__ src) {
+    const int r = blockIdx.x;
+    if (r >= n_rows) return;
+    const int pos = sp->cache_pos;
+    const int* rd = anc_base + (int64_t)(sp->parity ^ 1) * buf_stride + (int64_t)src[r] * n_ctx;
+    int* wr = anc_base + (int64_t)sp->parity * buf_stride + (int64_t)r * n_ctx;
+    for (int p = threadIdx.x; p <= pos && p < n_ctx; p += blockDim.x) wr[p] = (p == pos) ? r : rd[p];
+}
+void launch_anc_update(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, const StepParams* sp,
+                       const int* src, hipStream_t s) {
+    anc_update_kernel<<<n_rows, 128, 0, s>>>(anc_base, anc_buf_stride, n_ctx, n_rows, sp, src);
+}
+
+}  // namespace wrs

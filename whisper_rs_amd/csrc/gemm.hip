@@ -1,0 +1,473 @@
+// GEMM kernels for gfx950 (CDNA4), 64-wide wavefronts, MFMA.
+//
+//  * gemm_f16_kernel     C[M,N] = A[M,K] W[N,K]^T, fp16 in / fp32 accumulate, 128x128x64 tiles,
+//                        v_mfma_f32_16x16x32_f16.  A rows may overlap (lda < K): conv1d as implicit GEMM
+//                        (reference model.rs:421-422 conv1/conv2).  Replaces the tch `linear`/`conv1d`
+//                        call sites of the encoder and the cross-attention K/V projection
+//                        (reference model.rs:159-161,205,279-292).
+//  * gemm_skinny_kernel  decode-step GEMM, M <= 320 rows: weight-streaming (HBM-bound), every
+//                        weight fragment is read once with lane-linear 16-byte loads.
+//  * gemm_f32_kernel     exact-f32 MFMA (v_mfma_f32_16x16x4_f32) for the STFT-as-GEMM and the mel
+//                        filterbank (reference audio.rs:236-252).
+//
+// Weights are pre-packed in MFMA fragment order (kernels.h) so a wave reads 1 KiB contiguous per
+// fragment and LDS fragment reads are lane-linear ds_read_b128 (conflict-free, no swizzle needed).
+// MFMA operand roles: A-operand = weight fragment (rows = n), B-operand = activation fragment
+// (cols = m); D[n][m]: lane l holds m = l&15 and n = 4*(l>>4)+r, r=0..3 -> 4 consecutive output
+// columns per lane = one vector store.
+#include "kernels.h"
+
+namespace wrs {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// ------------------------------------------------------------------------------------------ packing
+size_t packed_weight_halfs(int64_t n_pad, int64_t k_pad) { return (size_t)n_pad * (size_t)k_pad; }
+
+template <bool CONV>
+__global__ void pack_weight_kernel(const float* __restrict__ w, int64_t n, int64_t k, int64_t ldw, int64_t conv_c,
+                                   half_t* __restrict__ out, int64_t n_pad, int64_t k_pad) {
+    const int64_t ksteps = k_pad / 32;
+    const int64_t total = (n_pad / 16) * ksteps * 64;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(i & 63);
+        const int64_t f = i >> 6;
+        const int64_t nt = f / ksteps, ks = f % ksteps;
+        const int64_t row = nt * 16 + (l & 15);
+        const int64_t k0 = ks * 32 + 8 * (l >> 4);
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t kk = k0 + j;
+            float x = 0.f;
+            if (row < n && kk < k) {
+                if (CONV) {
+                    const int64_t tap = kk / conv_c, c = kk % conv_c;  // w[n][c][tap]
+                    x = w[(row * conv_c + c) * 3 + tap];
+                } else {
+                    x = w[row * ldw + kk];
+                }
+            }
+            v[j] = (_Float16)x;
+        }
+        *reinterpret_cast<half8*>(out + i * 8) = v;
+    }
+}
+
+void launch_pack_weight_f32(const float* w, int64_t n, int64_t k, int64_t ldw, half_t* out, int64_t n_pad, int64_t k_pad,
+                            hipStream_t s) {
+    const int64_t total = (n_pad / 16) * (k_pad / 32) * 64;
+    const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 8192);
+    pack_weight_kernel<false><<<blocks, 256, 0, s>>>(w, n, k, ldw, 0, out, n_pad, k_pad);
+}
+void launch_pack_conv_weight_f32(const float* w, int64_t n, int64_t c, half_t* out, int64_t n_pad, int64_t k_pad,
+                                 hipStream_t s) {
+    const int64_t total = (n_pad / 16) * (k_pad / 32) * 64;
+    const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 8192);
+    pack_weight_kernel<true><<<blocks, 256, 0, s>>>(w, n, 3 * c, 0, c, out, n_pad, k_pad);
+}
+
+__global__ void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (_Float16)in[i];
+}
+__global__ void f16_to_f32_kernel(const half_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+void launch_f32_to_f16(const float* in, half_t* out, int64_t n, hipStream_t s) {
+    f32_to_f16_kernel<<<(int)std::min<int64_t>(cdiv(n, 256), 8192), 256, 0, s>>>(in, out, n);
+}
+void launch_f16_to_f32(const half_t* in, float* out, int64_t n, hipStream_t s) {
+    f16_to_f32_kernel<<<(int)std::min<int64_t>(cdiv(n, 256), 8192), 256, 0, s>>>(in, out, n);
+}
+
+// ------------------------------------------------------------------------------------------ big GEMM
+struct GemmParams {
+    const half_t* a;
+    int64_t lda, a_rpb, a_bs;
+    const half_t* wp;
+    int M, N, K, ksteps;
+    // epilogue
+    const float* bias;
+    float scale;
+    int scale_n_end;
+    int act;
+    const float* residual;
+    const float* posemb;
+    void* c;
+    int c_f32;
+    int64_t ldc, c_rpb, c_brows, c_roff;
+};
+
+__global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
+    // [buf][0 = activations, 1 = weights][fragment][lane] ; 2*2*16*64*16 B = 64 KiB
+    __shared__ half8 lds[2][2][16][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+
+    const half_t* a_ptr[4];
+    const half_t* w_ptr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = wave * 4 + j, t16 = f >> 1, ks = f & 1;
+        int64_t m = m0 + t16 * 16 + (lane & 15);
+        if (m > p.M - 1) m = p.M - 1;
+        a_ptr[j] = p.a + (m / p.a_rpb) * p.a_bs + (m % p.a_rpb) * p.lda + ks * 32 + (lane >> 4) * 8;
+        w_ptr[j] = p.wp + ((int64_t)(n0 / 16 + t16) * p.ksteps + ks) * 512 + lane * 8;
+    }
+
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int wy = wave >> 1, wx = wave & 1;
+    const int nk = p.K / 64;
+    half8 ra[4], rw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ra[j] = *reinterpret_cast<const half8*>(a_ptr[j]);
+        rw[j] = *reinterpret_cast<const half8*>(w_ptr[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        lds[0][0][wave * 4 + j][lane] = ra[j];
+        lds[0][1][wave * 4 + j][lane] = rw[j];
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ra[j] = *reinterpret_cast<const half8*>(a_ptr[j] + (int64_t)(kt + 1) * 64);
+                rw[j] = *reinterpret_cast<const half8*>(w_ptr[j] + (int64_t)(kt + 1) * 1024);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 wf[4], af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = lds[buf][1][(wy * 4 + i) * 2 + ks][lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = lds[buf][0][(wx * 4 + j) * 2 + ks][lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lds[buf ^ 1][0][wave * 4 + j][lane] = ra[j];
+                lds[buf ^ 1][1][wave * 4 + j][lane] = rw[j];
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue
+    const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t m = m0 + wx * 64 + j * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int64_t mb = m / p.c_rpb, mr = m % p.c_rpb;
+        const int64_t crow = mb * p.c_brows + mr + p.c_roff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wy * 64 + i * 16 + 4 * (lane >> 4);
+            if (n >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = n + r;
+                if (nn < p.N) {
+                    float x = v[r];
+                    if (p.bias) x += p.bias[nn];
+                    if (nn < p.scale_n_end) x *= p.scale;
+                    if (p.act) x = gelu_exact(x);
+                    if (p.posemb) x += p.posemb[mr * p.N + nn];
+                    if (p.residual) x += p.residual[crow * p.ldc + nn];
+                    v[r] = x;
+                }
+            }
+            if (vec_ok) {
+                if (p.c_f32) {
+                    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.c) + crow * p.ldc + n) =
+                        floatx4{v[0], v[1], v[2], v[3]};
+                } else {
+                    *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.c) + crow * p.ldc + n) =
+                        half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r < p.N) {
+                        if (p.c_f32) reinterpret_cast<float*>(p.c)[crow * p.ldc + n + r] = v[r];
+                        else reinterpret_cast<half_t*>(p.c)[crow * p.ldc + n + r] = (_Float16)v[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t N, int64_t K, const GemmEpi& e,
+                     hipStream_t s) {
+    WRS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_f16: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    WRS_REQUIRE(A.lda % 8 == 0 && A.batch_stride % 8 == 0, "gemm_f16: A strides must be multiples of 8 halfs");
+    WRS_REQUIRE(M < (1ll << 31) && N < (1ll << 31), "gemm_f16: shape too large");
+    GemmParams p;
+    p.a = A.a; p.lda = A.lda; p.a_rpb = A.rows_per_batch; p.a_bs = A.batch_stride;
+    p.wp = w_packed; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ksteps = (int)(K / 32);
+    p.bias = e.bias; p.scale = e.scale; p.scale_n_end = e.scale_n_end; p.act = e.act;
+    p.residual = e.residual; p.posemb = e.posemb; p.c = e.c; p.c_f32 = e.c_f32; p.ldc = e.ldc;
+    p.c_rpb = e.c_rows_per_batch; p.c_brows = e.c_batch_rows; p.c_roff = e.c_row_off;
+    dim3 grid((unsigned)cdiv(M, 128), (unsigned)cdiv(N, 128));
+    gemm_f16_kernel<<<grid, 256, 0, s>>>(p);
+}
+
+// ------------------------------------------------------------------------------------------ skinny GEMM
+struct SkinnyParams {
+    const half_t* a;
+    const half_t* wp;
+    int M, N, K, ksteps, ksplit, m_pad;
+    int kind;
+    const float* bias;
+    float scale;
+    int scale_n_end;
+    int act;
+    void* c;
+    int64_t ldc;
+    half_t* kcache;
+    half_t* vcache;
+    int d_model;
+    int64_t cache_row_stride;
+    int phys_mul;
+    const StepParams* sp;
+};
+
+int skinny_m_pad(int M) {
+    static const int opts[] = {1, 2, 4, 6, 8, 10, 12, 16, 20};
+    for (int o : opts)
+        if (o * 16 >= M) return o * 16;
+    return -1;
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) {
+    __shared__ float red[4][MT][4][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kps = p.ksteps / p.ksplit;
+    const int ks_begin = blockIdx.y * kps, ks_end = ks_begin + kps;
+
+    floatx4 acc[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const half_t* w0 = p.wp + ((int64_t)(blockIdx.x * 2 + 0) * p.ksteps) * 512 + lane * 8;
+    const half_t* w1 = p.wp + ((int64_t)(blockIdx.x * 2 + 1) * p.ksteps) * 512 + lane * 8;
+    const half_t* ab = p.a + (int64_t)(lane & 15) * p.K + (lane >> 4) * 8;
+
+    for (int ks = ks_begin + wave; ks < ks_end; ks += 4) {
+        const half8 f0 = *reinterpret_cast<const half8*>(w0 + (int64_t)ks * 512);
+        const half8 f1 = *reinterpret_cast<const half8*>(w1 + (int64_t)ks * 512);
+        half8 af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            af[mt] = *reinterpret_cast<const half8*>(ab + (int64_t)mt * 16 * p.K + ks * 32);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, af[mt], acc[0][mt], 0, 0, 0);
+            acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, af[mt], acc[1][mt], 0, 0, 0);
+        }
+    }
+
+    const int cache_pos = (p.kind == SK_QKV_SELF) ? p.sp->cache_pos : 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][mt][r][lane] = acc[t][mt][r];
+        __syncthreads();
+        for (int vl = tid; vl < MT * 64; vl += 256) {
+            const int mt = vl >> 6, ll = vl & 63;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (red[0][mt][r][ll] + red[1][mt][r][ll]) + (red[2][mt][r][ll] + red[3][mt][r][ll]);
+            const int m = mt * 16 + (ll & 15);
+            const int n = (blockIdx.x * 2 + t) * 16 + 4 * (ll >> 4);
+            if (m >= p.M || n >= p.N) continue;
+            if (p.kind == SK_SLAB) {
+                float* dst = reinterpret_cast<float*>(p.c) + ((int64_t)blockIdx.y * p.m_pad + m) * p.N + n;
+                *reinterpret_cast<floatx4*>(dst) = floatx4{v[0], v[1], v[2], v[3]};
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = n + r;
+                if (nn < p.N) {
+                    float x = v[r];
+                    if (p.bias) x += p.bias[nn];
+                    if (nn < p.scale_n_end) x *= p.scale;
+                    if (p.act) x = gelu_exact(x);
+                    v[r] = x;
+                }
+            }
+            if (p.kind == SK_F32) {
+                float* dst = reinterpret_cast<float*>(p.c) + (int64_t)m * p.ldc + n;
+                if (((p.ldc & 3) == 0) && n + 4 <= p.N) {
+                    *reinterpret_cast<floatx4*>(dst) = floatx4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) dst[r] = v[r];
+                }
+            } else if (p.kind == SK_F16) {
+                half_t* dst = reinterpret_cast<half_t*>(p.c) + (int64_t)m * p.ldc + n;
+                *reinterpret_cast<half4*>(dst) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            } else {  // SK_QKV_SELF
+                const int region = n / p.d_model, nl = n - region * p.d_model;
+                half_t* dst;
+                if (region == 0) dst = reinterpret_cast<half_t*>(p.c) + (int64_t)m * p.ldc + nl;
+                else {
+                    half_t* base = region == 1 ? p.kcache : p.vcache;
+                    dst = base + (int64_t)m * p.phys_mul * p.cache_row_stride + (int64_t)cache_pos * p.d_model + nl;
+                }
+                *reinterpret_cast<half4*>(dst) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_gemm_skinny(const half_t* a, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K, int ksplit,
+                        const SkinnyEpi& e, hipStream_t s) {
+    const int m_pad = skinny_m_pad(M);
+    WRS_REQUIRE(m_pad > 0, "gemm_skinny: M=%d exceeds 320 rows", M);
+    WRS_REQUIRE(K % 32 == 0 && n_pad % 32 == 0 && N <= n_pad, "gemm_skinny: bad shape N=%ld n_pad=%ld K=%ld", (long)N,
+                (long)n_pad, (long)K);
+    WRS_REQUIRE(ksplit >= 1 && (K / 32) % ksplit == 0, "gemm_skinny: ksplit %d does not divide K/32=%ld", ksplit, (long)(K / 32));
+    WRS_REQUIRE(ksplit == 1 || e.kind == SK_SLAB, "gemm_skinny: split-K needs the slab epilogue");
+    if (e.kind == SK_F16 || e.kind == SK_QKV_SELF || e.kind == SK_SLAB)
+        WRS_REQUIRE(N % 4 == 0 && (e.kind == SK_SLAB || e.ldc % 4 == 0), "gemm_skinny: N and ldc must be multiples of 4");
+    if (e.kind == SK_QKV_SELF)
+        WRS_REQUIRE(e.sp && e.kcache && e.vcache && e.d_model > 0 && N == 3 * e.d_model && e.d_model % 4 == 0, "gemm_skinny: bad QKV epilogue");
+    SkinnyParams p;
+    p.a = a; p.wp = w_packed; p.M = M; p.N = (int)N; p.K = (int)K; p.ksteps = (int)(K / 32); p.ksplit = ksplit;
+    p.m_pad = m_pad; p.kind = e.kind; p.bias = e.bias; p.scale = e.scale; p.scale_n_end = e.scale_n_end;
+    p.act = e.act; p.c = e.c; p.ldc = e.ldc; p.kcache = e.kcache; p.vcache = e.vcache; p.d_model = (int)e.d_model;
+    p.cache_row_stride = e.cache_row_stride; p.phys_mul = e.phys_mul; p.sp = e.sp;
+    dim3 grid((unsigned)(n_pad / 32), (unsigned)ksplit);
+    switch (m_pad / 16) {
+#define WRS_SK(MT) case MT: gemm_skinny_kernel<MT><<<grid, 256, 0, s>>>(p); break;
+        WRS_SK(1) WRS_SK(2) WRS_SK(4) WRS_SK(6) WRS_SK(8) WRS_SK(10) WRS_SK(12) WRS_SK(16) WRS_SK(20)
+#undef WRS_SK
+        default: WRS_THROW(WRS_EINVAL, "gemm_skinny: unsupported m_pad %d", m_pad);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ f32 GEMM
+__device__ __forceinline__ int float_order_key(float f) {
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, int64_t lda, int64_t rpb, int64_t bs,
+                                                       const float* __restrict__ w, int64_t ldw, int M, int N, int K,
+                                                       float* __restrict__ c, int64_t ldc, int* __restrict__ maxbuf) {
+    __shared__ float As[64][17];
+    __shared__ float Ws[64][17];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int lrow = tid >> 2, kq = (tid & 3) * 4;
+    int64_t m = m0 + lrow;
+    if (m > M - 1) m = M - 1;
+    const float* ap = a + (m / rpb) * bs + (m % rpb) * lda + kq;
+    const float* wp = w + (int64_t)(n0 + lrow) * ldw + kq;  // W allocated with round_up(N, 64) rows
+
+    floatx4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const floatx4 av = *reinterpret_cast<const floatx4*>(ap + k0);
+        const floatx4 wv = *reinterpret_cast<const floatx4*>(wp + k0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            As[lrow][kq + r] = av[r];
+            Ws[lrow][kq + r] = wv[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float wf[2], af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[i] = Ws[wy * 32 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) af[j] = As[wx * 32 + j * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t mm = m0 + wx * 32 + j * 16 + (lane & 15);
+        if (mm >= M) continue;
+        float row_max = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = n0 + wy * 32 + i * 16 + 4 * (lane >> 4);
+            if (MODE == 0) {
+                const int b0 = n >> 1;
+                if (b0 < ldc) c[mm * ldc + b0] = acc[i][j][0] * acc[i][j][0] + acc[i][j][1] * acc[i][j][1];
+                if (b0 + 1 < ldc) c[mm * ldc + b0 + 1] = acc[i][j][2] * acc[i][j][2] + acc[i][j][3] * acc[i][j][3];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r < N) {
+                        const float x = log10f(fmaxf(acc[i][j][r], 1e-10f));
+                        c[mm * ldc + n + r] = x;
+                        row_max = fmaxf(row_max, x);
+                    }
+                }
+            }
+        }
+        if (MODE == 1 && row_max > -3.0e38f) atomicMax(maxbuf + mm / rpb, float_order_key(row_max));
+    }
+}
+
+void launch_gemm_f32(const float* a, int64_t lda, int64_t rows_per_batch, int64_t batch_stride, const float* w,
+                     int64_t ldw, int64_t M, int64_t N, int64_t K, int mode, float* c, int64_t ldc, float* maxbuf,
+                     hipStream_t s) {
+    WRS_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldw % 4 == 0 && batch_stride % 4 == 0, "gemm_f32: alignment");
+    WRS_REQUIRE(M > 0 && M < (1ll << 31), "gemm_f32: bad M");
+    dim3 grid((unsigned)cdiv(M, 64), (unsigned)cdiv(N, 64));
+    if (mode == 0)
+        gemm_f32_kernel<0><<<grid, 256, 0, s>>>(a, lda, rows_per_batch, batch_stride, w, ldw, (int)M, (int)N, (int)K, c, ldc, nullptr);
+    else
+        gemm_f32_kernel<1><<<grid, 256, 0, s>>>(a, lda, rows_per_batch, batch_stride, w, ldw, (int)M, (int)N, (int)K, c, ldc,
+                                                reinterpret_cast<int*>(maxbuf));
+}
+
+}  // namespace wrs

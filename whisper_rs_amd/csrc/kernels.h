@@ -1,0 +1,145 @@
+// Kernel launcher declarations (gfx950 HIP).  All launchers enqueue on the given stream and
+// never synchronise.  Shapes are validated on the host before launch (a faulting kernel can
+// reset the whole node).
+#pragma once
+#include "common.h"
+
+namespace wrs {
+
+// per-step scalars that live in device memory so that one captured hipGraph serves every step
+struct StepParams {
+    int cache_pos;       // self-attention K/V slot written by this step (= tokens so far - 1)
+    int pos_idx;         // positional-embedding row (reference quirk Q2: loop index)
+    int parity;          // ancestry ping-pong: read anc[parity ^ 1], write anc[parity]
+    int first_step;      // tokens.size(1) == sample_begin (filters)
+    int want_no_speech;  // compute softmax(raw logits)[no_speech]
+    int n_rows;          // live rows this step
+    int pad0, pad1;
+};
+// followed in the same allocation by: int tokens[cap]; int src[cap]; int ts_mode[cap];
+
+// ---------------------------------------------------------------- weights packing
+// packed MFMA-fragment layout of a [N, K] row-major matrix: [Npad/16][K/32][64 lanes][8 halfs],
+// element (nt, ks, l, j) = W[nt*16 + (l & 15)][ks*32 + 8*(l >> 4) + j]; rows >= N are zero.
+size_t packed_weight_halfs(int64_t n_pad, int64_t k_pad);
+void launch_pack_weight_f32(const float* w, int64_t n, int64_t k, int64_t ldw, half_t* out, int64_t n_pad,
+                            int64_t k_pad, hipStream_t s);
+// conv weight [N, C, 3] -> [N, 3*C] with k = tap*C + c  (implicit-GEMM order), then packed
+void launch_pack_conv_weight_f32(const float* w, int64_t n, int64_t c, half_t* out, int64_t n_pad, int64_t k_pad,
+                                 hipStream_t s);
+void launch_f32_to_f16(const float* in, half_t* out, int64_t n, hipStream_t s);
+void launch_f16_to_f32(const half_t* in, float* out, int64_t n, hipStream_t s);
+
+// ---------------------------------------------------------------- big GEMM (encoder, cross-KV)
+struct GemmEpi {
+    const float* bias = nullptr;      // [N]
+    float scale = 1.f;                // applied to columns n < scale_n_end after bias
+    int scale_n_end = 0;
+    int act = 0;                      // 1 = exact (erf) GELU
+    const float* residual = nullptr;  // fp32, same addressing as C; may alias C
+    const float* posemb = nullptr;    // fp32 [c_rows_per_batch, N] added after activation
+    void* c = nullptr;
+    int c_f32 = 0;
+    int64_t ldc = 0;
+    int64_t c_rows_per_batch = 1ll << 40;  // C row of m = (m / rpb) * c_batch_rows + m % rpb + c_row_off
+    int64_t c_batch_rows = 0;
+    int64_t c_row_off = 0;
+};
+struct GemmA {
+    const half_t* a = nullptr;
+    int64_t lda = 0;                       // halfs between consecutive rows (may be < K: overlapping rows)
+    int64_t rows_per_batch = 1ll << 40;    // A row of m = a + (m / rpb) * batch_stride + (m % rpb) * lda
+    int64_t batch_stride = 0;
+};
+// C[M, N] = A[M, K] * W[N, K]^T ; K multiple of 64; W packed with n_pad multiple of 128
+void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t N, int64_t K, const GemmEpi& epi,
+                     hipStream_t s);
+
+// ---------------------------------------------------------------- skinny GEMM (decode, M <= 320)
+enum SkinnyKind { SK_F16 = 0, SK_F32 = 1, SK_SLAB = 2, SK_QKV_SELF = 3 };
+struct SkinnyEpi {
+    int kind = SK_F16;
+    const float* bias = nullptr;
+    float scale = 1.f;
+    int scale_n_end = 0;
+    int act = 0;
+    void* c = nullptr;   // SK_F16: half [M, N]; SK_F32: float [M, N]; SK_SLAB: float [ksplit][m_pad][N]; SK_QKV_SELF: q half [M, D]
+    int64_t ldc = 0;
+    // SK_QKV_SELF: N = 3*D; n in [D,2D) -> kcache, [2D,3D) -> vcache at [phys_row][cache_pos][n]
+    half_t* kcache = nullptr;
+    half_t* vcache = nullptr;
+    int64_t d_model = 0;
+    int64_t cache_row_stride = 0;  // halfs per physical row (= n_ctx * D)
+    int phys_mul = 1;
+    const StepParams* sp = nullptr;
+};
+// C[M, N] = A[M, K] (row-major fp16, lda = K) * W^T ; W packed (n_pad multiple of 32, K multiple of 128)
+void launch_gemm_skinny(const half_t* a, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K,
+                        int ksplit, const SkinnyEpi& epi, hipStream_t s);
+int skinny_m_pad(int M);
+
+// ---------------------------------------------------------------- f32 GEMM (STFT, mel filterbank)
+// mode 0: power spectrum. C[m][n/2] = acc[2b]^2 + acc[2b+1]^2 (interleaved re/im columns), ldc floats
+// mode 1: log-mel.        C[m][n] = log10(max(acc, 1e-10)); atomic max per batch into maxbuf[m / rows_per_batch]
+void launch_gemm_f32(const float* a, int64_t lda, int64_t rows_per_batch, int64_t batch_stride, const float* w,
+                     int64_t ldw, int64_t M, int64_t N, int64_t K, int mode, float* c, int64_t ldc, float* maxbuf,
+                     hipStream_t s);
+
+// ---------------------------------------------------------------- mel
+void launch_reflect_pad(const float* audio, int64_t n_batch, int64_t n, float* out, int64_t out_stride, hipStream_t s);
+void launch_fill_f32(float* p, float v, int64_t n, hipStream_t s);
+// logmel [B*F, 80] (time-major, log10 domain) -> out [B, 80, F] = (max(x, max_b - 8) + 4) / 4
+void launch_mel_finalize(const float* logmel, const float* maxbuf, int64_t n_batch, int64_t n_frames, float* out,
+                         hipStream_t s);
+// mel [B, 80, F] f32 -> encoder input [B, 3002, 80] fp16 (time-major, one zero row each side), frames
+// seek..seek+3000, zero (0.0 in log-mel space, reference audio.rs:226) past the end
+void launch_mel_prep(const float* mel, int64_t n_batch, int64_t n_frames, int64_t mel_batch_stride, int64_t seek,
+                     half_t* out, hipStream_t s);
+
+// ---------------------------------------------------------------- norms / embedding
+// y = LN(x) * g + b (eps 1e-5); x fp32 [M, D]; out16 and/or out32 may be null
+void launch_layernorm(const float* x, const float* g, const float* b, int64_t M, int D, half_t* out16, float* out32,
+                      hipStream_t s);
+// x[m] += bias + sum_s slab[s][m]; xn = LN(x).  slab [ksplit][m_pad][D]
+void launch_finish_residual_ln(float* x, const float* slab, int ksplit, int m_pad, const float* bias, const float* g,
+                               const float* b, int M, int D, half_t* xn, hipStream_t s);
+// x[r] = emb[token[r]] + pos[pos_idx]; xn = LN(x)
+void launch_embed_ln(const half_t* emb, const float* pos, const StepParams* sp, const int* tokens, const float* g,
+                     const float* b, int M, int D, float* x, half_t* xn, hipStream_t s);
+
+// ---------------------------------------------------------------- attention
+// packed K/V for one (batch, head): Kp [Tp/16][2][64][8], Vp [Tp/32][4][64][8] (Tp = round_up(T, 32))
+size_t packed_kv_halfs_per_head(int T);
+// src [n_batch*T, ld] fp16 row-major; K at column k_off + h*64, V at v_off + h*64
+void launch_pack_kv(const half_t* src, int64_t ld, int64_t k_off, int64_t v_off, int n_batch, int T, int H,
+                    half_t* kp, half_t* vp, hipStream_t s);
+// encoder-style: every 16-query tile of [n_batch, Tq] attends to all T keys. q [n_batch*Tq, ldq] at col h*64
+void launch_attn_full(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_batch, int Tq, int T,
+                      int H, half_t* out, int64_t ldo, hipStream_t s);
+// decode cross-attention: the G (<=16) rows of one audio share that audio's packed K/V
+void launch_attn_cross(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_audio, int G, int T,
+                       int H, half_t* out, int64_t ldo, hipStream_t s);
+// decode self-attention over the ancestry-indirected K/V cache; one wave per (row, head)
+void launch_attn_self(const half_t* q, int64_t ldq, const half_t* kc, const half_t* vc, const int* anc_base,
+                      int64_t anc_buf_stride, int n_ctx, int n_rows, int phys_mul, int H, int D, const StepParams* sp,
+                      half_t* out, int64_t ldo, hipStream_t s);
+void launch_anc_init(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_phys_rows, int G, hipStream_t s);
+void launch_anc_update(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, const StepParams* sp,
+                       const int* src, hipStream_t s);
+
+// ---------------------------------------------------------------- logits: filters + log-softmax + top-k
+struct FilterCfg {
+    int n_vocab;
+    int ts_begin, eot, no_timestamps, no_speech, space;
+    int suppress_blank;         // SuppressBlank enabled
+    int timestamps;             // TimestampTokens enabled
+    int max_initial_ts_index;   // -1: None
+    const int* suppress_ids;    // device
+    int n_suppress;
+};
+// logits [n_rows, V] f32 device.  ts_mode[r]: 0 none, 1 mask [ts_begin, V), 2 mask [0, eot)   (timestamp_tokens.rs:47-66)
+// out_lp/out_id [n_rows, k] (device-visible), no_speech [n_rows] (written when sp->want_no_speech)
+void launch_filter_topk(const float* logits, int n_rows, const FilterCfg& cfg, const StepParams* sp, const int* ts_mode,
+                        int k, float* out_lp, int* out_id, float* no_speech, float* out_filtered, hipStream_t s);
+
+}  // namespace wrs

@@ -1,0 +1,244 @@
+// Fused logit filters + log-softmax + top-k over the 51 864/51 865-entry vocabulary (gfx950).
+//
+// Replaces, per decode step and per row, the reference's chain of separate ATen calls and host
+// round-trips:
+//   SuppressBlank      (filter/suppress_blanks.rs:38-43)   index_fill_(-inf) at first step
+//   SuppressTokens     (filter/suppress_tokens.rs:21-23)   index_fill_(-inf)
+//   TimestampTokens    (filter/timestamp_tokens.rs:33-97)  pairing masks, first-step masks, and the
+//                      "timestamp mass > best text token" rule (log_softmax + logsumexp + max,
+//                      4 scalar device reads per row in the reference)
+//   log_softmax        (extractor/beam_search.rs:37, greedy.rs:31)
+//   topk(beam+1)       (extractor/beam_search.rs:62-65), argmax (greedy.rs:25)
+//   no-speech prob     (decode/mod.rs:250-255) softmax(raw logits)[no_speech] at step 0
+// One 256-thread workgroup per row; every reduction is a 64-lane wave reduction followed by a
+// 4-wave LDS combine.  The row (207 KB f32) is streamed from L2 three times; nothing is written
+// back except k (logprob, id) pairs.
+#include "kernels.h"
+
+namespace wrs {
+
+#define TOPK_MAX 8
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_add(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ float block_add(float v, float* sh) {
+    v = wave_add(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+struct FilterParams {
+    const float* logits;
+    int n_vocab, ts_begin, eot, no_timestamps, no_speech, space;
+    int suppress_blank, timestamps, mit;
+    const int* suppress_ids;
+    int n_suppress;
+    const StepParams* sp;
+    const int* ts_mode;
+    int k;
+    float* out_lp;
+    int* out_id;
+    float* no_speech_out;
+    float* out_filtered;
+};
+
+__global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) {
+    extern __shared__ unsigned int smem[];  // bitmask of statically suppressed ids: ceil(V/32) words
+    __shared__ float red[4];
+    __shared__ float cand_v[256];
+    __shared__ int cand_i[256];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int V = p.n_vocab;
+    const float* x = p.logits + (int64_t)row * V;
+    const int first = p.sp->first_step;
+    const int nwords = (V + 31) / 32;
+
+    // ---- no-speech probability on the raw logits (decode/mod.rs:250-255)
+    if (p.sp->want_no_speech && p.no_speech_out) {
+        float m = -INFINITY;
+        for (int v = tid; v < V; v += 256) m = fmaxf(m, x[v]);
+        m = block_max(m, red);
+        float su = 0.f;
+        for (int v = tid; v < V; v += 256) su += __expf(x[v] - m);
+        su = block_add(su, red);
+        if (tid == 0) p.no_speech_out[row] = __expf(x[p.no_speech] - m) / su;
+    }
+
+    // ---- static suppression mask
+    for (int w = tid; w < nwords; w += 256) smem[w] = 0u;
+    __syncthreads();
+    for (int i = tid; i < p.n_suppress; i += 256) {
+        const int id = p.suppress_ids[i];
+        if (id >= 0 && id < V) atomicOr(&smem[id >> 5], 1u << (id & 31));
+    }
+    if (tid == 0) {
+        if (p.suppress_blank && first) {  // suppress_blanks.rs:38-43
+            atomicOr(&smem[p.space >> 5], 1u << (p.space & 31));
+            atomicOr(&smem[p.eot >> 5], 1u << (p.eot & 31));
+        }
+        if (p.timestamps) atomicOr(&smem[p.no_timestamps >> 5], 1u << (p.no_timestamps & 31));  // timestamp_tokens.rs:37-41
+    }
+    __syncthreads();
+
+    // ---- range masks of TimestampTokens (timestamp_tokens.rs:47-78)
+    int lo = 0, hi = V;         // allowed index range [lo, hi) after the pairing / first-step rules
+    if (p.timestamps) {
+        const int mode = p.ts_mode[row];
+        if (mode == 1) hi = min(hi, p.ts_begin);   // last two sampled were timestamps: must be text
+        else if (mode == 2) lo = max(lo, p.eot);   // last was a lone timestamp: no text below eot
+        if (first) {
+            lo = max(lo, p.ts_begin);
+            if (p.mit >= 0) hi = min(hi, p.ts_begin + p.mit + 1);
+        }
+    }
+    const int tsb = p.timestamps ? p.ts_begin : V;
+
+    // ---- pass A: maxima of the text and timestamp ranges
+    float mt = -INFINITY, ms = -INFINITY;
+    for (int v = tid; v < V; v += 256) {
+        float val = x[v];
+        if (v < lo || v >= hi || ((smem[v >> 5] >> (v & 31)) & 1u)) val = -INFINITY;
+        if (v < tsb) mt = fmaxf(mt, val);
+        else ms = fmaxf(ms, val);
+    }
+    mt = block_max(mt, red);
+    ms = block_max(ms, red);
+    const float mall = fmaxf(mt, ms);
+
+    // ---- pass B: sum-exp of both ranges relative to the global max (log_softmax, timestamp_tokens.rs:82)
+    float st = 0.f, ss = 0.f, ss_own = 0.f;
+    for (int v = tid; v < V; v += 256) {
+        float val = x[v];
+        if (v < lo || v >= hi || ((smem[v >> 5] >> (v & 31)) & 1u)) val = -INFINITY;
+        if (v < tsb) st += __expf(val - mall);
+        else {
+            ss += __expf(val - mall);
+            if (val != -INFINITY) ss_own += __expf(val - ms);  // (-inf) - (-inf) would be NaN when the range is empty
+        }
+    }
+    st = block_add(st, red);
+    ss = block_add(ss, red);
+    ss_own = block_add(ss_own, red);
+
+    bool mask_text = false;
+    float lse = mall + __logf(st + ss);
+    if (p.timestamps) {
+        // timestamp_tokens.rs:83-96: logsumexp(logprobs[ts_begin:]) > max(logprobs[:ts_begin]) ?
+        const float ts_lp = (ms == -INFINITY) ? -INFINITY : (ms - lse) + __logf(ss_own);
+        const float text_lp = mt - lse;
+        if (ts_lp > text_lp) {
+            mask_text = true;
+            lse = ms + __logf(ss_own);  // log_softmax after masking the text range (beam_search.rs:37)
+        }
+    }
+    if (mask_text) lo = max(lo, p.ts_begin);
+
+    if (p.out_filtered) {
+        float* o = p.out_filtered + (int64_t)row * V;
+        for (int v = tid; v < V; v += 256) {
+            float val = x[v];
+            if (v < lo || v >= hi || ((smem[v >> 5] >> (v & 31)) & 1u)) val = -INFINITY;
+            o[v] = val;
+        }
+    }
+
+    // ---- pass C: top-k.  Each thread keeps its TOPK_MAX best (value desc, index asc on ties), then k rounds
+    // of block arg-max over the threads' current heads.
+    float tv[TOPK_MAX];
+    int ti[TOPK_MAX];
+#pragma unroll
+    for (int j = 0; j < TOPK_MAX; ++j) {
+        tv[j] = -INFINITY;
+        ti[j] = 0x7fffffff;
+    }
+    const int K = p.k;
+    for (int v = tid; v < V; v += 256) {
+        float val = x[v];
+        if (v < lo || v >= hi || ((smem[v >> 5] >> (v & 31)) & 1u)) continue;
+        if (val > tv[TOPK_MAX - 1] || (val == tv[TOPK_MAX - 1] && v < ti[TOPK_MAX - 1])) {
+            // insertion into the sorted list (static indexing keeps tv/ti in registers)
+            float cv = val;
+            int ci = v;
+#pragma unroll
+            for (int j = 0; j < TOPK_MAX; ++j) {
+                const bool better = cv > tv[j] || (cv == tv[j] && ci < ti[j]);
+                if (better) {
+                    const float ov = tv[j];
+                    const int oi = ti[j];
+                    tv[j] = cv;
+                    ti[j] = ci;
+                    cv = ov;
+                    ci = oi;
+                }
+            }
+        }
+    }
+    int head = 0;
+    for (int round = 0; round < K; ++round) {
+        float hv = -INFINITY;
+        int hi_ = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < TOPK_MAX; ++j)
+            if (j == head) {
+                hv = tv[j];
+                hi_ = ti[j];
+            }
+        cand_v[tid] = hv;
+        cand_i[tid] = hi_;
+        __syncthreads();
+        for (int stride = 128; stride > 0; stride >>= 1) {
+            if (tid < stride) {
+                const float ov = cand_v[tid + stride];
+                const int oi = cand_i[tid + stride];
+                if (ov > cand_v[tid] || (ov == cand_v[tid] && oi < cand_i[tid])) {
+                    cand_v[tid] = ov;
+                    cand_i[tid] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        const float bv = cand_v[0];
+        const int bi = cand_i[0];
+        __syncthreads();
+        if (bi == hi_ && hi_ != 0x7fffffff) head++;
+        if (tid == 0) {
+            p.out_lp[row * K + round] = (bi == 0x7fffffff) ? -INFINITY : bv - lse;
+            p.out_id[row * K + round] = (bi == 0x7fffffff) ? -1 : bi;
+        }
+    }
+}
+
+void launch_filter_topk(const float* logits, int n_rows, const FilterCfg& cfg, const StepParams* sp, const int* ts_mode,
+                        int k, float* out_lp, int* out_id, float* no_speech, float* out_filtered, hipStream_t s) {
+    WRS_REQUIRE(k >= 1 && k <= TOPK_MAX, "filter_topk: k=%d not in 1..%d", k, TOPK_MAX);
+    WRS_REQUIRE(cfg.n_vocab > 0 && cfg.ts_begin >= 0 && cfg.ts_begin <= cfg.n_vocab && cfg.eot < cfg.n_vocab &&
+                    cfg.no_timestamps < cfg.n_vocab && cfg.no_speech < cfg.n_vocab && cfg.space < cfg.n_vocab,
+                "filter_topk: token ids out of range for vocab %d", cfg.n_vocab);
+    FilterParams p;
+    p.logits = logits; p.n_vocab = cfg.n_vocab; p.ts_begin = cfg.ts_begin; p.eot = cfg.eot;
+    p.no_timestamps = cfg.no_timestamps; p.no_speech = cfg.no_speech; p.space = cfg.space;
+    p.suppress_blank = cfg.suppress_blank; p.timestamps = cfg.timestamps; p.mit = cfg.max_initial_ts_index;
+    p.suppress_ids = cfg.suppress_ids; p.n_suppress = cfg.n_suppress; p.sp = sp; p.ts_mode = ts_mode; p.k = k;
+    p.out_lp = out_lp; p.out_id = out_id; p.no_speech_out = no_speech; p.out_filtered = out_filtered;
+    const size_t shmem = (size_t)((cfg.n_vocab + 31) / 32) * 4;
+    filter_topk_kernel<<<n_rows, 256, shmem, s>>>(p);
+}
+
+}  // namespace wrs

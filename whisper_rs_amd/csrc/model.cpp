@@ -1,0 +1,541 @@
+// Model: weight intake/packing, AudioEncoder forward, TextDecoder single-token step.
+// Restates the *structure* of reference src/model.rs on top of the fused gfx950 kernels:
+//   AudioEncoder::forward        model.rs:417-441  -> Model::encoder_from_mel_t
+//   ResidualAttentionBlock       model.rs:301-319  -> per-layer kernel sequences below
+//   TextDecoder::forward_ext     model.rs:490-522  -> Model::decoder_step (one token per row)
+//   Cached<Linear> K/V caches    model.rs:37-98    -> DecState (pre-allocated ring + ancestry table)
+#include "model.h"
+#include <cmath>
+
+namespace wrs {
+
+// ------------------------------------------------------------------------------------------ timer
+StageTimer::~StageTimer() {
+    for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : pool) (void)hipEventDestroy(e);
+}
+int StageTimer::slot(const char* name) {
+    for (size_t i = 0; i < entries.size(); ++i)
+        if (entries[i].name == name || strcmp(entries[i].name, name) == 0) return (int)i;
+    Entry e; e.name = name;
+    entries.push_back(e);
+    return (int)entries.size() - 1;
+}
+hipEvent_t StageTimer::get_event() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+void StageTimer::begin(int, hipStream_t s, hipEvent_t& a) {
+    a = get_event();
+    HIP_CHECK(hipEventRecord(a, s));
+}
+void StageTimer::end(int idx, hipStream_t s, hipEvent_t a, double bytes, double flops) {
+    hipEvent_t b = get_event();
+    HIP_CHECK(hipEventRecord(b, s));
+    pending.push_back({idx, a, b});
+    entries[idx].launches += 1;
+    entries[idx].bytes += bytes;
+    entries[idx].flops += flops;
+}
+void StageTimer::collect() {
+    for (auto& p : pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) entries[p.idx].ms += ms;
+        pool.push_back(p.a);
+        pool.push_back(p.b);
+    }
+    pending.clear();
+}
+void StageTimer::reset() {
+    collect();
+    entries.clear();
+}
+
+// ------------------------------------------------------------------------------------------ model
+Model::~Model() {
+    if (stream) (void)hipStreamDestroy(stream);
+    delete timer;
+}
+
+void Model::use() const { HIP_CHECK(hipSetDevice(device)); }
+
+static bool expected_shape(const Model& m, const std::string& name, std::vector<int64_t>& shape) {
+    const int64_t D = m.dims.n_audio_states, Dt = m.dims.n_text_states;
+    auto ends = [&](const char* suf) {
+        const size_t n = strlen(suf);
+        return name.size() >= n && name.compare(name.size() - n, n, suf) == 0;
+    };
+    const bool is_enc = name.rfind("encoder.", 0) == 0;
+    const int64_t d = is_enc ? D : Dt;
+    if (name == "encoder.conv1.weight") { shape = {D, WRS_N_MELS, 3}; return true; }
+    if (name == "encoder.conv2.weight") { shape = {D, D, 3}; return true; }
+    if (name == "encoder.conv1.bias" || name == "encoder.conv2.bias") { shape = {D}; return true; }
+    if (name == "decoder.token_embedding.weight") { shape = {m.dims.n_vocab, Dt}; return true; }
+    if (name == "decoder.positional_embedding") { shape = {m.dims.n_text_ctxs, Dt}; return true; }
+    if (name.find(".blocks.") == std::string::npos) {
+        if (name == "encoder.ln_post.weight" || name == "encoder.ln_post.bias" || name == "decoder.ln.weight" ||
+            name == "decoder.ln.bias") { shape = {d}; return true; }
+        return false;
+    }
+    if (ends(".mlp.0.weight")) { shape = {4 * d, d}; return true; }
+    if (ends(".mlp.0.bias")) { shape = {4 * d}; return true; }
+    if (ends(".mlp.2.weight")) { shape = {d, 4 * d}; return true; }
+    if (ends(".query.weight") || ends(".key.weight") || ends(".value.weight") || ends(".out.weight")) { shape = {d, d}; return true; }
+    if (ends(".bias") || ends("_ln.weight")) { shape = {d}; return true; }
+    return false;
+}
+
+void Model::set_tensor(const std::string& name, int dtype, const int64_t* shape, int ndim, const void* data, int mem_kind) {
+    WRS_REQUIRE(!finalized, "set_tensor(%s): model already finalized", name.c_str());
+    WRS_REQUIRE(data && shape && ndim >= 1 && ndim <= 3, "set_tensor(%s): bad arguments", name.c_str());
+    WRS_REQUIRE(dtype == WRS_F32 || dtype == WRS_F16, "set_tensor(%s): dtype must be WRS_F32 or WRS_F16", name.c_str());
+    std::vector<int64_t> want;
+    WRS_REQUIRE(expected_shape(*this, name, want), "set_tensor: unknown tensor name '%s'", name.c_str());
+    WRS_REQUIRE((int)want.size() == ndim, "set_tensor(%s): rank %d, expected %d", name.c_str(), ndim, (int)want.size());
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        WRS_REQUIRE(shape[i] == want[i], "set_tensor(%s): dim %d is %ld, expected %ld", name.c_str(), i, (long)shape[i], (long)want[i]);
+        n *= shape[i];
+    }
+    use();
+    DevBuf buf;
+    buf.alloc((size_t)n * 4);
+    const hipMemcpyKind kind = mem_kind == WRS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (dtype == WRS_F32) {
+        HIP_CHECK(hipMemcpyAsync(buf.p, data, (size_t)n * 4, kind, stream));
+    } else {
+        DevBuf tmp;
+        tmp.alloc((size_t)n * 2);
+        HIP_CHECK(hipMemcpyAsync(tmp.p, data, (size_t)n * 2, kind, stream));
+        launch_f16_to_f32(tmp.as<half_t>(), buf.as<float>(), n, stream);
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+    staging[name] = std::move(buf);
+}
+
+static const float* need(Model& m, const std::string& name) {
+    auto it = m.staging.find(name);
+    if (it == m.staging.end()) WRS_THROW(WRS_ESTATE, "finalize: tensor '%s' was never set", name.c_str());
+    return it->second.as<float>();
+}
+
+static half_t* pack_linear(Model& m, const float* w, int64_t n, int64_t k) {
+    const int64_t n_pad = round_up(n, 128), k_pad = round_up(k, 64);
+    DevBuf b;
+    b.alloc(packed_weight_halfs(n_pad, k_pad) * 2);
+    launch_pack_weight_f32(w, n, k, k, b.as<half_t>(), n_pad, k_pad, m.stream);
+    half_t* p = b.as<half_t>();
+    m.owned.push_back(std::move(b));
+    return p;
+}
+
+static float* keep_f32(Model& m, const float* src, int64_t n) {
+    DevBuf b;
+    b.alloc((size_t)n * 4);
+    HIP_CHECK(hipMemcpyAsync(b.p, src, (size_t)n * 4, hipMemcpyDeviceToDevice, m.stream));
+    float* p = b.as<float>();
+    m.owned.push_back(std::move(b));
+    return p;
+}
+
+// concatenate row-blocks of [d, k] matrices into one staging buffer, then pack
+static half_t* pack_concat(Model& m, std::vector<const float*> parts, int64_t d, int64_t k) {
+    DevBuf cat;
+    cat.alloc((size_t)parts.size() * d * k * 4);
+    for (size_t i = 0; i < parts.size(); ++i)
+        HIP_CHECK(hipMemcpyAsync(cat.as<float>() + i * d * k, parts[i], (size_t)d * k * 4, hipMemcpyDeviceToDevice, m.stream));
+    half_t* p = pack_linear(m, cat.as<float>(), (int64_t)parts.size() * d, k);
+    HIP_CHECK(hipStreamSynchronize(m.stream));
+    return p;
+}
+
+static float* concat_bias(Model& m, std::vector<const float*> parts, int64_t d) {
+    DevBuf b;
+    b.alloc(parts.size() * d * 4);  // zero-initialised
+    for (size_t i = 0; i < parts.size(); ++i)
+        if (parts[i]) HIP_CHECK(hipMemcpyAsync(b.as<float>() + i * d, parts[i], (size_t)d * 4, hipMemcpyDeviceToDevice, m.stream));
+    float* p = b.as<float>();
+    m.owned.push_back(std::move(b));
+    return p;
+}
+
+static void build_block(Model& m, BlockW& bw, const std::string& pre, int64_t d, bool cross) {
+    auto t = [&](const char* s) { return need(m, pre + s); };
+    bw.attn_ln_g = keep_f32(m, t(".attn_ln.weight"), d);
+    bw.attn_ln_b = keep_f32(m, t(".attn_ln.bias"), d);
+    bw.qkv_w = pack_concat(m, {t(".attn.query.weight"), t(".attn.key.weight"), t(".attn.value.weight")}, d, d);
+    bw.qkv_b = concat_bias(m, {t(".attn.query.bias"), nullptr, t(".attn.value.bias")}, d);
+    bw.out_w = pack_linear(m, t(".attn.out.weight"), d, d);
+    bw.out_b = keep_f32(m, t(".attn.out.bias"), d);
+    if (cross) {
+        bw.cross_ln_g = keep_f32(m, t(".cross_attn_ln.weight"), d);
+        bw.cross_ln_b = keep_f32(m, t(".cross_attn_ln.bias"), d);
+        bw.cq_w = pack_linear(m, t(".cross_attn.query.weight"), d, d);
+        bw.cq_b = keep_f32(m, t(".cross_attn.query.bias"), d);
+        bw.ckv_w = pack_concat(m, {t(".cross_attn.key.weight"), t(".cross_attn.value.weight")}, d, d);
+        bw.ckv_b = concat_bias(m, {nullptr, t(".cross_attn.value.bias")}, d);
+        bw.cout_w = pack_linear(m, t(".cross_attn.out.weight"), d, d);
+        bw.cout_b = keep_f32(m, t(".cross_attn.out.bias"), d);
+    }
+    bw.mlp_ln_g = keep_f32(m, t(".mlp_ln.weight"), d);
+    bw.mlp_ln_b = keep_f32(m, t(".mlp_ln.bias"), d);
+    bw.mlp0_w = pack_linear(m, t(".mlp.0.weight"), 4 * d, d);
+    bw.mlp0_b = keep_f32(m, t(".mlp.0.bias"), 4 * d);
+    bw.mlp2_w = pack_linear(m, t(".mlp.2.weight"), d, 4 * d);
+    bw.mlp2_b = keep_f32(m, t(".mlp.2.bias"), d);
+    HIP_CHECK(hipStreamSynchronize(m.stream));
+    // release this block's staging memory early (large-v2 staging is 6 GB fp32)
+    for (auto it = m.staging.begin(); it != m.staging.end();)
+        if (it->first.rfind(pre + ".", 0) == 0) it = m.staging.erase(it);
+        else ++it;
+}
+
+void Model::finalize() {
+    WRS_REQUIRE(!finalized, "finalize: already finalized");
+    use();
+    WRS_REQUIRE(dims.n_audio_states == dims.n_text_states, "n_audio_states != n_text_states is not supported (cross-attention width)");
+    D = (int)dims.n_text_states;
+    H = (int)dims.n_text_heads;
+    WRS_REQUIRE(dims.n_audio_heads == dims.n_text_heads, "n_audio_heads != n_text_heads is not supported");
+    WRS_REQUIRE(D == H * 64, "head_dim must be 64 (n_state %d, heads %d)", D, H);
+    WRS_REQUIRE(D % 64 == 0 && D <= 2048, "n_state %d unsupported (multiple of 64, <= 2048)", D);
+    L_enc = (int)dims.n_audio_layers;
+    L_dec = (int)dims.n_text_layers;
+    V = (int)dims.n_vocab;
+    T = (int)dims.n_audio_ctxs;
+    n_ctx = (int)dims.n_text_ctxs;
+    WRS_REQUIRE(T * 2 == WRS_N_FRAMES, "n_audio_ctxs must be %d", WRS_N_FRAMES / 2);
+    WRS_REQUIRE(n_ctx >= 2 && n_ctx <= 512, "n_text_ctxs %d unsupported (<= 512)", n_ctx);
+    v_pad = round_up(V, 128);
+
+    // conv weights in implicit-GEMM order
+    {
+        const int64_t k1 = round_up(3 * WRS_N_MELS, 64), k2 = round_up(3 * (int64_t)D, 64), n_pad = round_up(D, 128);
+        DevBuf b1, b2;
+        b1.alloc(packed_weight_halfs(n_pad, k1) * 2);
+        b2.alloc(packed_weight_halfs(n_pad, k2) * 2);
+        launch_pack_conv_weight_f32(need(*this, "encoder.conv1.weight"), D, WRS_N_MELS, b1.as<half_t>(), n_pad, k1, stream);
+        launch_pack_conv_weight_f32(need(*this, "encoder.conv2.weight"), D, D, b2.as<half_t>(), n_pad, k2, stream);
+        conv1_w = b1.as<half_t>();
+        conv2_w = b2.as<half_t>();
+        owned.push_back(std::move(b1));
+        owned.push_back(std::move(b2));
+        conv1_b = keep_f32(*this, need(*this, "encoder.conv1.bias"), D);
+        conv2_b = keep_f32(*this, need(*this, "encoder.conv2.bias"), D);
+    }
+    // sinusoidal positions, exactly the f32 op sequence of reference model.rs:102-112
+    {
+        std::vector<float> tab((size_t)T * D);
+        const int half = D / 2;
+        const float inc = std::log(10000.0f) / (float)(half - 1);
+        for (int t = 0; t < T; ++t)
+            for (int c = 0; c < half; ++c) {
+                const float inv = std::exp(-inc * (float)c);
+                const float st = (float)t * inv;
+                tab[(size_t)t * D + c] = std::sin(st);
+                tab[(size_t)t * D + half + c] = std::cos(st);
+            }
+        DevBuf b;
+        b.alloc(tab.size() * 4);
+        HIP_CHECK(hipMemcpy(b.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        enc_pos = b.as<float>();
+        owned.push_back(std::move(b));
+    }
+    enc.resize(L_enc);
+    for (int i = 0; i < L_enc; ++i) build_block(*this, enc[i], "encoder.blocks." + std::to_string(i), D, false);
+    ln_post_g = keep_f32(*this, need(*this, "encoder.ln_post.weight"), D);
+    ln_post_b = keep_f32(*this, need(*this, "encoder.ln_post.bias"), D);
+
+    {
+        const float* e = need(*this, "decoder.token_embedding.weight");
+        DevBuf b;
+        b.alloc((size_t)V * D * 2);
+        launch_f32_to_f16(e, b.as<half_t>(), (int64_t)V * D, stream);
+        emb16 = b.as<half_t>();
+        owned.push_back(std::move(b));
+        emb_p = pack_linear(*this, e, V, D);
+        dec_pos = keep_f32(*this, need(*this, "decoder.positional_embedding"), (int64_t)n_ctx * D);
+    }
+    dec.resize(L_dec);
+    for (int i = 0; i < L_dec; ++i) build_block(*this, dec[i], "decoder.blocks." + std::to_string(i), D, true);
+    ln_g = keep_f32(*this, need(*this, "decoder.ln.weight"), D);
+    ln_b = keep_f32(*this, need(*this, "decoder.ln.bias"), D);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    staging.clear();
+    finalized = true;
+}
+
+// ------------------------------------------------------------------------------------------ encoder
+void Model::ensure_encoder_ws(int n) {
+    EncoderWorkspace& w = enc_ws;
+    if (n <= w.cap) return;
+    const int64_t M = (int64_t)n * T;
+    w.mel_t.alloc(((size_t)n * 3002 * 80 + 256) * 2);
+    w.c1.alloc(((size_t)n * 3001 * D + 256) * 2);
+    w.x.alloc((size_t)M * D * 4);
+    w.xn.alloc((size_t)M * D * 2);
+    w.qkv.alloc((size_t)M * 3 * D * 2);
+    w.kp.alloc((size_t)n * H * packed_kv_halfs_per_head(T) * 2);
+    w.vp.alloc((size_t)n * H * packed_kv_halfs_per_head(T) * 2);
+    w.att.alloc((size_t)M * D * 2);
+    w.h.alloc((size_t)M * 4 * D * 2);
+    w.xa16.alloc((size_t)M * D * 2);
+    w.xa32.alloc((size_t)M * D * 4);
+    w.cap = n;
+}
+
+void Model::load_mel(const float* mel, int n, int mem_kind, int64_t n_frames, int64_t seek) {
+    ensure_encoder_ws(n);
+    const size_t bytes = (size_t)n * 80 * n_frames * 4;
+    const float* src = mel;
+    DevBuf tmp;
+    if (mem_kind == WRS_MEM_HOST) {
+        tmp.alloc(bytes);
+        HIP_CHECK(hipMemcpyAsync(tmp.p, mel, bytes, hipMemcpyHostToDevice, stream));
+        src = tmp.as<float>();
+    }
+    launch_mel_prep(src, n, n_frames, 80 * n_frames, seek, enc_ws.mel_t.as<half_t>(), stream);
+    if (mem_kind == WRS_MEM_HOST) HIP_CHECK(hipStreamSynchronize(stream));  // tmp is freed on return
+}
+
+void Model::encoder_from_mel_t(int n) {
+    WRS_REQUIRE(finalized, "model not finalized");
+    WRS_REQUIRE(n >= 1 && n <= enc_ws.cap, "encoder: bad window count %d", n);
+    EncoderWorkspace& w = enc_ws;
+    const int64_t M = (int64_t)n * T;
+    const float scale = std::pow((float)(D / H), -0.25f);
+    const double dM = (double)M, dD = (double)D;
+    {   // conv1 + GELU (model.rs:421) as implicit GEMM, K = 3*80 (padded to 256 with zero weights)
+        Timed tm(timer, "enc_conv1", stream, 0, 2.0 * n * 3000 * 240 * dD);
+        GemmA A{w.mel_t.as<half_t>(), 80, 3000, 3002 * 80};
+        GemmEpi e;
+        e.bias = conv1_b; e.act = 1; e.c = w.c1.p; e.c_f32 = 0; e.ldc = D;
+        e.c_rows_per_batch = 3000; e.c_batch_rows = 3001; e.c_row_off = 1;
+        launch_gemm_f16(A, conv1_w, (int64_t)n * 3000, D, round_up(240, 64), e, stream);
+    }
+    {   // conv2 (stride 2) + GELU + permute + positional embedding (model.rs:422-431)
+        Timed tm(timer, "enc_conv2", stream, 0, 2.0 * dM * 3 * dD * dD);
+        GemmA A{w.c1.as<half_t>(), 2 * (int64_t)D, T, 3001 * (int64_t)D};
+        GemmEpi e;
+        e.bias = conv2_b; e.act = 1; e.posemb = enc_pos; e.c = w.x.p; e.c_f32 = 1; e.ldc = D;
+        e.c_rows_per_batch = T; e.c_batch_rows = T; e.c_row_off = 0;
+        launch_gemm_f16(A, conv2_w, M, D, 3 * (int64_t)D, e, stream);
+    }
+    for (int l = 0; l < L_enc; ++l) {
+        const BlockW& b = enc[l];
+        {
+            Timed tm(timer, "enc_ln", stream, dM * dD * 6);
+            launch_layernorm(w.x.as<float>(), b.attn_ln_g, b.attn_ln_b, M, D, w.xn.as<half_t>(), nullptr, stream);
+        }
+        {
+            Timed tm(timer, "enc_gemm_qkv", stream, 0, 2.0 * dM * 3 * dD * dD);
+            GemmA A{w.xn.as<half_t>(), D};
+            GemmEpi e;
+            e.bias = b.qkv_b; e.scale = scale; e.scale_n_end = 2 * D; e.c = w.qkv.p; e.ldc = 3 * D;
+            launch_gemm_f16(A, b.qkv_w, M, 3 * D, D, e, stream);
+        }
+        {
+            Timed tm(timer, "enc_pack_kv", stream, dM * dD * 2 * 2 * 2);
+            launch_pack_kv(w.qkv.as<half_t>(), 3 * D, D, 2 * D, n, T, H, w.kp.as<half_t>(), w.vp.as<half_t>(), stream);
+        }
+        {
+            Timed tm(timer, "enc_attn", stream, 0, 4.0 * n * (double)T * T * dD);
+            launch_attn_full(w.qkv.as<half_t>(), 3 * D, w.kp.as<half_t>(), w.vp.as<half_t>(), n, T, T, H, w.att.as<half_t>(), D, stream);
+        }
+        {
+            Timed tm(timer, "enc_gemm_out", stream, 0, 2.0 * dM * dD * dD);
+            GemmA A{w.att.as<half_t>(), D};
+            GemmEpi e;
+            e.bias = b.out_b; e.residual = w.x.as<float>(); e.c = w.x.p; e.c_f32 = 1; e.ldc = D;
+            launch_gemm_f16(A, b.out_w, M, D, D, e, stream);
+        }
+        {
+            Timed tm(timer, "enc_ln", stream, dM * dD * 6);
+            launch_layernorm(w.x.as<float>(), b.mlp_ln_g, b.mlp_ln_b, M, D, w.xn.as<half_t>(), nullptr, stream);
+        }
+        {
+            Timed tm(timer, "enc_gemm_mlp1", stream, 0, 2.0 * dM * 4 * dD * dD);
+            GemmA A{w.xn.as<half_t>(), D};
+            GemmEpi e;
+            e.bias = b.mlp0_b; e.act = 1; e.c = w.h.p; e.ldc = 4 * D;
+            launch_gemm_f16(A, b.mlp0_w, M, 4 * D, D, e, stream);
+        }
+        {
+            Timed tm(timer, "enc_gemm_mlp2", stream, 0, 2.0 * dM * 4 * dD * dD);
+            GemmA A{w.h.as<half_t>(), 4 * (int64_t)D};
+            GemmEpi e;
+            e.bias = b.mlp2_b; e.residual = w.x.as<float>(); e.c = w.x.p; e.c_f32 = 1; e.ldc = D;
+            launch_gemm_f16(A, b.mlp2_w, M, D, 4 * D, e, stream);
+        }
+    }
+    {
+        Timed tm(timer, "enc_ln", stream, dM * dD * 10);
+        launch_layernorm(w.x.as<float>(), ln_post_g, ln_post_b, M, D, w.xa16.as<half_t>(), w.xa32.as<float>(), stream);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ decoder
+void Model::init_state(DecState& st, int a_cap, int group) {
+    WRS_REQUIRE(finalized, "model not finalized");
+    WRS_REQUIRE(a_cap >= 1 && group >= 1 && group <= 16, "decoder state: bad capacity (audios %d, group %d)", a_cap, group);
+    const int r_cap = a_cap * group;
+    const int m_pad = skinny_m_pad(r_cap);
+    WRS_REQUIRE(m_pad > 0, "decoder state: %d rows exceed the 320-row limit of the decode kernels", r_cap);
+    use();
+    st.a_cap = a_cap; st.group = group; st.r_cap = r_cap; st.m_pad = m_pad;
+    const size_t per_head = packed_kv_halfs_per_head(T);
+    st.cross_kp.alloc((size_t)L_dec * a_cap * H * per_head * 2);
+    st.cross_vp.alloc((size_t)L_dec * a_cap * H * per_head * 2);
+    st.kc.alloc((size_t)L_dec * r_cap * n_ctx * D * 2);
+    st.vc.alloc((size_t)L_dec * r_cap * n_ctx * D * 2);
+    st.anc.alloc((size_t)2 * r_cap * n_ctx * 4);
+    st.x.alloc((size_t)m_pad * D * 4);
+    st.xn.alloc((size_t)m_pad * D * 2);
+    st.q.alloc((size_t)m_pad * D * 2);
+    st.att.alloc((size_t)m_pad * D * 2);
+    st.h.alloc((size_t)m_pad * 4 * D * 2);
+    st.slab.alloc((size_t)st.slab_ksplit_cap * m_pad * D * 4);
+    st.logits.alloc((size_t)r_cap * V * 4);
+    st.ckv_tmp.alloc((size_t)a_cap * T * 2 * D * 2);
+    st.sp_dev.alloc(st.sp_bytes());
+    st.sp_host.alloc(st.sp_bytes());
+    st.topk.alloc((size_t)r_cap * 17 * 4);
+    st.len = 0;
+    st.parity = 0;
+    st.n_audio = 0;
+    st.pending_src.clear();
+}
+
+void Model::load_cross_kv(DecState& st, const half_t* xa16, int n_audio) {
+    WRS_REQUIRE(n_audio >= 1 && n_audio <= st.a_cap, "cross K/V: %d audios exceed capacity %d", n_audio, st.a_cap);
+    const int64_t M = (int64_t)n_audio * T;
+    const float scale = std::pow((float)(D / H), -0.25f);
+    const size_t per_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
+    for (int l = 0; l < L_dec; ++l) {
+        const BlockW& b = dec[l];
+        {
+            Timed tm(timer, "dec_cross_kv_proj", stream, 0, 2.0 * (double)M * 2 * D * (double)D);
+            GemmA A{xa16, D};
+            GemmEpi e;
+            e.bias = b.ckv_b; e.scale = scale; e.scale_n_end = D; e.c = st.ckv_tmp.p; e.ldc = 2 * D;
+            launch_gemm_f16(A, b.ckv_w, M, 2 * D, D, e, stream);
+        }
+        {
+            Timed tm(timer, "dec_cross_kv_pack", stream, (double)M * D * 2 * 2 * 2);
+            launch_pack_kv(st.ckv_tmp.as<half_t>(), 2 * D, 0, D, n_audio, T, H, st.cross_kp.as<half_t>() + l * per_layer,
+                           st.cross_vp.as<half_t>() + l * per_layer, stream);
+        }
+    }
+    st.n_audio = n_audio;
+}
+
+static int pick_ksplit(int64_t N, int64_t K, int cap) {
+    const int ksteps = (int)(K / 32);
+    const int wgs = (int)(N / 32);
+    int ks = 1;
+    while (ks * 2 <= cap && wgs * ks * 2 <= 512 && ksteps % (ks * 2) == 0 && ksteps / (ks * 2) >= 4) ks *= 2;
+    return ks;
+}
+
+void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits) {
+    WRS_REQUIRE(rows >= 1 && rows * phys_mul <= st.r_cap * std::max(1, phys_mul) && rows <= st.r_cap, "decoder_step: bad row count %d", rows);
+    WRS_REQUIRE((rows - 1) * phys_mul < st.r_cap, "decoder_step: physical row out of range");
+    WRS_REQUIRE(rows % q_per_audio == 0 && rows / q_per_audio <= st.n_audio, "decoder_step: rows %d do not match %d audios x %d", rows, st.n_audio, q_per_audio);
+    const float scale = std::pow((float)(D / H), -0.25f);
+    const StepParams* sp = st.sp_d();
+    const int64_t anc_stride = (int64_t)st.r_cap * n_ctx;
+    const size_t kv_layer = (size_t)st.r_cap * n_ctx * D;
+    const size_t cross_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
+    const int n_audio = rows / q_per_audio;
+    const double wD = (double)D * D * 2;  // bytes of a [D, D] fp16 matrix
+    const int ks_d = pick_ksplit(D, D, st.slab_ksplit_cap), ks_4d = pick_ksplit(D, 4 * (int64_t)D, st.slab_ksplit_cap);
+
+    if (update_anc) {
+        Timed tm(timer, "dec_anc_update", stream);
+        launch_anc_update(st.anc.as<int>(), anc_stride, n_ctx, rows, sp, st.src_d(), stream);
+    }
+    {
+        Timed tm(timer, "dec_embed_ln", stream);
+        launch_embed_ln(emb16, dec_pos, sp, st.tokens_d(), dec[0].attn_ln_g, dec[0].attn_ln_b, rows, D, st.x.as<float>(),
+                        st.xn.as<half_t>(), stream);
+    }
+    for (int l = 0; l < L_dec; ++l) {
+        const BlockW& b = dec[l];
+        {
+            Timed tm(timer, "dec_gemm_qkv", stream, 3 * wD);
+            SkinnyEpi e;
+            e.kind = SK_QKV_SELF; e.bias = b.qkv_b; e.scale = scale; e.scale_n_end = 2 * D; e.c = st.q.p; e.ldc = D;
+            e.kcache = st.kc.as<half_t>() + l * kv_layer; e.vcache = st.vc.as<half_t>() + l * kv_layer;
+            e.d_model = D; e.cache_row_stride = (int64_t)n_ctx * D; e.phys_mul = phys_mul; e.sp = sp;
+            launch_gemm_skinny(st.xn.as<half_t>(), b.qkv_w, rows, 3 * D, round_up(3 * D, 128), D, 1, e, stream);
+        }
+        {
+            Timed tm(timer, "dec_attn_self", stream);
+            launch_attn_self(st.q.as<half_t>(), D, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer,
+                             st.anc.as<int>(), anc_stride, n_ctx, rows, phys_mul, H, D, sp, st.att.as<half_t>(), D, stream);
+        }
+        {
+            Timed tm(timer, "dec_gemm_out", stream, wD);
+            SkinnyEpi e;
+            e.kind = SK_SLAB; e.c = st.slab.p;
+            launch_gemm_skinny(st.att.as<half_t>(), b.out_w, rows, D, round_up(D, 128), D, ks_d, e, stream);
+        }
+        {
+            Timed tm(timer, "dec_finish_ln", stream);
+            launch_finish_residual_ln(st.x.as<float>(), st.slab.as<float>(), ks_d, st.m_pad_for(rows), b.out_b, b.cross_ln_g,
+                                      b.cross_ln_b, rows, D, st.xn.as<half_t>(), stream);
+        }
+        {
+            Timed tm(timer, "dec_gemm_cq", stream, wD);
+            SkinnyEpi e;
+            e.kind = SK_F16; e.bias = b.cq_b; e.scale = scale; e.scale_n_end = D; e.c = st.q.p; e.ldc = D;
+            launch_gemm_skinny(st.xn.as<half_t>(), b.cq_w, rows, D, round_up(D, 128), D, 1, e, stream);
+        }
+        {
+            Timed tm(timer, "dec_attn_cross", stream, (double)n_audio * 2.0 * T * D * 2.0);
+            launch_attn_cross(st.q.as<half_t>(), D, st.cross_kp.as<half_t>() + l * cross_layer,
+                              st.cross_vp.as<half_t>() + l * cross_layer, n_audio, q_per_audio, T, H, st.att.as<half_t>(), D, stream);
+        }
+        {
+            Timed tm(timer, "dec_gemm_out", stream, wD);
+            SkinnyEpi e;
+            e.kind = SK_SLAB; e.c = st.slab.p;
+            launch_gemm_skinny(st.att.as<half_t>(), b.cout_w, rows, D, round_up(D, 128), D, ks_d, e, stream);
+        }
+        {
+            Timed tm(timer, "dec_finish_ln", stream);
+            launch_finish_residual_ln(st.x.as<float>(), st.slab.as<float>(), ks_d, st.m_pad_for(rows), b.cout_b, b.mlp_ln_g,
+                                      b.mlp_ln_b, rows, D, st.xn.as<half_t>(), stream);
+        }
+        {
+            Timed tm(timer, "dec_gemm_mlp1", stream, 4 * wD);
+            SkinnyEpi e;
+            e.kind = SK_F16; e.bias = b.mlp0_b; e.act = 1; e.c = st.h.p; e.ldc = 4 * D;
+            launch_gemm_skinny(st.xn.as<half_t>(), b.mlp0_w, rows, 4 * D, round_up(4 * D, 128), D, 1, e, stream);
+        }
+        {
+            Timed tm(timer, "dec_gemm_mlp2", stream, 4 * wD);
+            SkinnyEpi e;
+            e.kind = SK_SLAB; e.c = st.slab.p;
+            launch_gemm_skinny(st.h.as<half_t>(), b.mlp2_w, rows, D, round_up(D, 128), 4 * (int64_t)D, ks_4d, e, stream);
+        }
+        {
+            Timed tm(timer, "dec_finish_ln", stream);
+            const float* g = (l + 1 < L_dec) ? dec[l + 1].attn_ln_g : ln_g;
+            const float* bb = (l + 1 < L_dec) ? dec[l + 1].attn_ln_b : ln_b;
+            launch_finish_residual_ln(st.x.as<float>(), st.slab.as<float>(), ks_4d, st.m_pad_for(rows), b.mlp2_b, g, bb, rows, D,
+                                      st.xn.as<half_t>(), stream);
+        }
+    }
+    if (want_logits) {
+        Timed tm(timer, "dec_gemm_logits", stream, (double)V * D * 2 + (double)rows * V * 4);
+        SkinnyEpi e;
+        e.kind = SK_F32; e.c = st.logits.p; e.ldc = V;
+        launch_gemm_skinny(st.xn.as<half_t>(), emb_p, rows, V, v_pad, D, 1, e, stream);
+    }
+}
+
+}  // namespace wrs

@@ -1,0 +1,163 @@
+// Host-side model, encoder workspace and decoder state (device memory owned here).
+#pragma once
+#include <map>
+#include <memory>
+#include "kernels.h"
+
+namespace wrs {
+
+struct BlockW {
+    float *attn_ln_g = nullptr, *attn_ln_b = nullptr;
+    half_t* qkv_w = nullptr;  // packed [3D, D]  (query | key | value)
+    float* qkv_b = nullptr;   // [3D], key part zero (reference model.rs:138-141: key has no bias)
+    half_t* out_w = nullptr;
+    float* out_b = nullptr;
+    // decoder only
+    float *cross_ln_g = nullptr, *cross_ln_b = nullptr;
+    half_t* cq_w = nullptr;
+    float* cq_b = nullptr;
+    half_t* ckv_w = nullptr;  // packed [2D, D] (key | value)
+    float* ckv_b = nullptr;
+    half_t* cout_w = nullptr;
+    float* cout_b = nullptr;
+    float *mlp_ln_g = nullptr, *mlp_ln_b = nullptr;
+    half_t* mlp0_w = nullptr;
+    float* mlp0_b = nullptr;
+    half_t* mlp2_w = nullptr;
+    float* mlp2_b = nullptr;
+};
+
+struct EncoderWorkspace {
+    int cap = 0;  // windows
+    DevBuf mel_t, c1, x, xn, qkv, kp, vp, att, h, xa16, xa32;
+};
+
+// decoder K/V caches + per-step scratch for up to `a_cap` audios x `group` rows
+struct DecState {
+    int a_cap = 0, group = 1, r_cap = 0, m_pad = 0;
+    int n_audio = 0;  // audios whose cross K/V are loaded
+    DevBuf cross_kp, cross_vp;  // [L][a_cap][H][Tp*64]
+    DevBuf kc, vc;              // [L][r_cap][n_ctx][D]
+    DevBuf anc;                 // [2][r_cap][n_ctx]
+    DevBuf x, xn, q, att, h, slab, logits, ckv_tmp;
+    DevBuf sp_dev;              // StepParams + tokens[r_cap] + src[r_cap] + ts_mode[r_cap]
+    PinnedBuf sp_host;
+    PinnedBuf topk;             // lp [r_cap*8] f32 | id [r_cap*8] i32 | no_speech [r_cap] f32
+    int slab_ksplit_cap = 16;
+    int len = 0;                // cached self-attention positions (stage API)
+    int parity = 0;
+    std::vector<int> pending_src;  // stage API: update_cache() to apply at the next forward
+    int m_pad_for(int rows) const { return skinny_m_pad(rows); }  // slab row stride used by the skinny GEMM for `rows`
+    StepParams* sp_h() { return sp_host.as<StepParams>(); }
+    int* tokens_h() { return reinterpret_cast<int*>(sp_host.as<char>() + sizeof(StepParams)); }
+    int* src_h() { return tokens_h() + r_cap; }
+    int* tsmode_h() { return src_h() + r_cap; }
+    const StepParams* sp_d() const { return sp_dev.as<StepParams>(); }
+    const int* tokens_d() const { return reinterpret_cast<const int*>(sp_dev.as<char>() + sizeof(StepParams)); }
+    const int* src_d() const { return tokens_d() + r_cap; }
+    const int* tsmode_d() const { return src_d() + r_cap; }
+    size_t sp_bytes() const { return sizeof(StepParams) + (size_t)3 * r_cap * sizeof(int); }
+    float* topk_lp() { return topk.as<float>(); }
+    int* topk_id() { return reinterpret_cast<int*>(topk.as<float>() + (size_t)r_cap * 8); }
+    float* no_speech_h() { return topk.as<float>() + (size_t)r_cap * 16; }
+    float* topk_lp_d() { return topk.dev_as<float>(); }
+    int* topk_id_d() { return reinterpret_cast<int*>(topk.dev_as<float>() + (size_t)r_cap * 8); }
+    float* no_speech_d() { return topk.dev_as<float>() + (size_t)r_cap * 16; }
+};
+
+struct StageTimer;
+
+struct Model {
+    wrs_model_dims dims{};
+    int device = 0;
+    int D = 0, H = 0, L_enc = 0, L_dec = 0, V = 0, T = 0, n_ctx = 0;
+    int64_t v_pad = 0;
+    bool finalized = false;
+    hipStream_t stream = nullptr;
+
+    std::map<std::string, DevBuf> staging;  // fp32 tensors as loaded
+    std::vector<DevBuf> owned;              // packed / converted tensors
+
+    // encoder
+    half_t* conv1_w = nullptr; float* conv1_b = nullptr;
+    half_t* conv2_w = nullptr; float* conv2_b = nullptr;
+    float* enc_pos = nullptr;  // sinusoids [T, D] fp32 (reference model.rs:102-112, computed not loaded)
+    std::vector<BlockW> enc;
+    float *ln_post_g = nullptr, *ln_post_b = nullptr;
+    // decoder
+    half_t* emb16 = nullptr;   // [V, D] row-major (embedding lookup)
+    half_t* emb_p = nullptr;   // packed [v_pad, D] (tied output projection, model.rs:521)
+    float* dec_pos = nullptr;  // [n_ctx, D]
+    std::vector<BlockW> dec;
+    float *ln_g = nullptr, *ln_b = nullptr;
+
+    EncoderWorkspace enc_ws;
+    std::unique_ptr<DecState> stage_state;  // used by the stage API (wrs_decoder_forward)
+    StageTimer* timer = nullptr;            // optional per-kernel timing sink
+
+    ~Model();
+    void set_tensor(const std::string& name, int dtype, const int64_t* shape, int ndim, const void* data, int mem_kind);
+    void finalize();
+    void use() const;  // hipSetDevice
+
+    // encoder over `n` windows; input already in enc_ws.mel_t ([n,3002,80] fp16). Output enc_ws.xa16 / xa32.
+    void ensure_encoder_ws(int n);
+    void encoder_from_mel_t(int n);
+    // upload mel [n,80,3000] f32 (host or device) into enc_ws.mel_t
+    void load_mel(const float* mel, int n, int mem_kind, int64_t n_frames, int64_t seek);
+
+    // decoder
+    void init_state(DecState& st, int a_cap, int group);
+    // cross-attention K/V for `n_audio` audios from xa16 [n_audio*T, D] fp16 (device)
+    void load_cross_kv(DecState& st, const half_t* xa16, int n_audio);
+    // one token per row. rows = logical rows this step; phys_mul = physical cache-row stride per logical row;
+    // q_per_audio = rows sharing one audio's cross K/V.  Step scalars / tokens / src must already be in st.sp_dev.
+    void decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits);
+};
+
+// log-mel on device (reference audio.rs:230-259).  audio_d [n_batch, n] f32 device -> out_d [n_batch, 80, n/160] f32 device
+struct MelWorkspace {
+    DevBuf padded, power, logmel, maxbuf, twiddle, filter;
+    bool tables_ready = false;
+    std::vector<float> filter_host;
+};
+void mel_filter_host(float* out /*80*201*/);
+void log_mel_device(MelWorkspace& ws, const float* audio_d, int64_t n_batch, int64_t n, const float* filter_host_or_null,
+                    float* out_d, hipStream_t s);
+
+// optional timing of named stages with HIP events on the model stream
+struct StageTimer {
+    struct Entry { const char* name; double ms = 0; int64_t launches = 0; double bytes = 0; double flops = 0; };
+    std::vector<Entry> entries;
+    struct Pending { int idx; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    bool enabled = false;
+    ~StageTimer();
+    int slot(const char* name);
+    hipEvent_t get_event();
+    void begin(int idx, hipStream_t s, hipEvent_t& a);
+    void end(int idx, hipStream_t s, hipEvent_t a, double bytes, double flops);
+    void collect();  // after a stream sync
+    void reset();
+};
+
+struct Timed {
+    StageTimer* t = nullptr;
+    int idx = 0;
+    hipStream_t s;
+    hipEvent_t a;
+    double bytes, flops;
+    Timed(StageTimer* tm, const char* name, hipStream_t st, double by = 0, double fl = 0) : s(st), bytes(by), flops(fl) {
+        if (tm && tm->enabled) {
+            t = tm;
+            idx = t->slot(name);
+            t->begin(idx, s, a);
+        }
+    }
+    ~Timed() {
+        if (t) t->end(idx, s, a, bytes, flops);
+    }
+};
+
+}  // namespace wrs

@@ -1,0 +1,22 @@
+// TranscribeTask (reference src/transcribe.rs:13-101).
+#pragma once
+#include "decode.h"
+
+namespace wrs {
+
+struct TranscribeTask {
+    Model* m = nullptr;
+    DecodeTask dt;
+    std::vector<int64_t> prompt;  // TranscribePrompt::Pretokenized
+    bool has_prompt = false;
+    bool condition = true;
+    MelWorkspace mel_ws;
+    DevBuf audio_dev, mel_dev;
+
+    void configure(Model* model, const wrs_token_ids& ids, const wrs_transcribe_options& o);
+    int64_t prepare_mel(const float* audio, int64_t n);  // whole-file log-mel into mel_dev; returns frames
+    void run(const float* audio, int64_t n, wrs_transcribe_output* out);
+    void run_chunked(const float* audio, int64_t n, int batch, wrs_transcribe_output* out);
+};
+
+}  // namespace wrs
