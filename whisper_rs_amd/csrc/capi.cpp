@@ -332,6 +332,25 @@ void wrs_transcribe_task_destroy(wrs_transcribe_task* t) {
     delete t;
 }
 
+// ------------------------------------------------------------------ debug hooks (not part of wrs.h)
+int wrs_debug_set_encoder_stop(wrs_model* h, int n_launches) { if (h) h->m.debug_enc_stop = n_launches; return 0; }
+// copy an internal encoder workspace buffer to host as f32. which: 0 x(f32) 1 xn 2 qkv 3 att 4 h 5 c1 6 mel_t 7 xa16
+int wrs_debug_read_encoder(wrs_model* h, int which, float* out, int64_t n) {
+    return guarded([&] {
+        Model& m = h->m;
+        m.use();
+        HIP_CHECK(hipStreamSynchronize(m.stream));
+        EncoderWorkspace& w = m.enc_ws;
+        if (which == 0) { HIP_CHECK(hipMemcpy(out, w.x.p, (size_t)n * 4, hipMemcpyDeviceToHost)); return; }
+        const DevBuf* b = which == 1 ? &w.xn : which == 2 ? &w.qkv : which == 3 ? &w.att : which == 4 ? &w.h : which == 5 ? &w.c1 : which == 6 ? &w.mel_t : &w.xa16;
+        DevBuf tmp;
+        tmp.alloc((size_t)n * 4);
+        launch_f16_to_f32(b->as<half_t>(), tmp.as<float>(), n, m.stream);
+        HIP_CHECK(hipStreamSynchronize(m.stream));
+        HIP_CHECK(hipMemcpy(out, tmp.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 // ------------------------------------------------------------------ measurement
 int wrs_decode_task_set_profiling(wrs_decode_task* t, int enabled) {
     return guarded([&] {

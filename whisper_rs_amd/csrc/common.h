@@ -76,7 +76,11 @@ struct DevBuf {
         if (n == 0) n = 256;
         n = (n + 255) & ~size_t(255);
         HIP_CHECK(hipMalloc(&p, n));
+        // hipMemset on device memory is asynchronous on the NULL stream, and the library's work streams are
+        // hipStreamNonBlocking (they do not order against it): wait here so that no later copy/kernel on a
+        // work stream can be overwritten by a late-landing zero fill.  Allocation is never on the hot path.
         HIP_CHECK(hipMemset(p, 0, n));
+        HIP_CHECK(hipDeviceSynchronize());
         bytes = n;
     }
     void ensure(size_t n) {

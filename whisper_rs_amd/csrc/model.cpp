@@ -308,6 +308,8 @@ void Model::encoder_from_mel_t(int n) {
     const int64_t M = (int64_t)n * T;
     const float scale = std::pow((float)(D / H), -0.25f);
     const double dM = (double)M, dD = (double)D;
+    int dbg_left = debug_enc_stop;  // debug hook: run only the first N launches (0 = all)
+#define WRS_DBG_STEP() do { if (debug_enc_stop > 0 && --dbg_left <= 0) return; } while (0)
     {   // conv1 + GELU (model.rs:421) as implicit GEMM, K = 3*80 (padded to 256 with zero weights)
         Timed tm(timer, "enc_conv1", stream, 0, 2.0 * n * 3000 * 240 * dD);
         GemmA A{w.mel_t.as<half_t>(), 80, 3000, 3002 * 80};
@@ -316,6 +318,7 @@ void Model::encoder_from_mel_t(int n) {
         e.c_rows_per_batch = 3000; e.c_batch_rows = 3001; e.c_row_off = 1;
         launch_gemm_f16(A, conv1_w, (int64_t)n * 3000, D, round_up(240, 64), e, stream);
     }
+    WRS_DBG_STEP();
     {   // conv2 (stride 2) + GELU + permute + positional embedding (model.rs:422-431)
         Timed tm(timer, "enc_conv2", stream, 0, 2.0 * dM * 3 * dD * dD);
         GemmA A{w.c1.as<half_t>(), 2 * (int64_t)D, T, 3001 * (int64_t)D};
@@ -324,12 +327,14 @@ void Model::encoder_from_mel_t(int n) {
         e.c_rows_per_batch = T; e.c_batch_rows = T; e.c_row_off = 0;
         launch_gemm_f16(A, conv2_w, M, D, 3 * (int64_t)D, e, stream);
     }
+    WRS_DBG_STEP();
     for (int l = 0; l < L_enc; ++l) {
         const BlockW& b = enc[l];
         {
             Timed tm(timer, "enc_ln", stream, dM * dD * 6);
             launch_layernorm(w.x.as<float>(), b.attn_ln_g, b.attn_ln_b, M, D, w.xn.as<half_t>(), nullptr, stream);
         }
+        WRS_DBG_STEP();
         {
             Timed tm(timer, "enc_gemm_qkv", stream, 0, 2.0 * dM * 3 * dD * dD);
             GemmA A{w.xn.as<half_t>(), D};
@@ -337,14 +342,17 @@ void Model::encoder_from_mel_t(int n) {
             e.bias = b.qkv_b; e.scale = scale; e.scale_n_end = 2 * D; e.c = w.qkv.p; e.ldc = 3 * D;
             launch_gemm_f16(A, b.qkv_w, M, 3 * D, D, e, stream);
         }
+        WRS_DBG_STEP();
         {
             Timed tm(timer, "enc_pack_kv", stream, dM * dD * 2 * 2 * 2);
             launch_pack_kv(w.qkv.as<half_t>(), 3 * D, D, 2 * D, n, T, H, w.kp.as<half_t>(), w.vp.as<half_t>(), stream);
         }
+        WRS_DBG_STEP();
         {
             Timed tm(timer, "enc_attn", stream, 0, 4.0 * n * (double)T * T * dD);
             launch_attn_full(w.qkv.as<half_t>(), 3 * D, w.kp.as<half_t>(), w.vp.as<half_t>(), n, T, T, H, w.att.as<half_t>(), D, stream);
         }
+        WRS_DBG_STEP();
         {
             Timed tm(timer, "enc_gemm_out", stream, 0, 2.0 * dM * dD * dD);
             GemmA A{w.att.as<half_t>(), D};
@@ -352,10 +360,12 @@ void Model::encoder_from_mel_t(int n) {
             e.bias = b.out_b; e.residual = w.x.as<float>(); e.c = w.x.p; e.c_f32 = 1; e.ldc = D;
             launch_gemm_f16(A, b.out_w, M, D, D, e, stream);
         }
+        WRS_DBG_STEP();
         {
             Timed tm(timer, "enc_ln", stream, dM * dD * 6);
             launch_layernorm(w.x.as<float>(), b.mlp_ln_g, b.mlp_ln_b, M, D, w.xn.as<half_t>(), nullptr, stream);
         }
+        WRS_DBG_STEP();
         {
             Timed tm(timer, "enc_gemm_mlp1", stream, 0, 2.0 * dM * 4 * dD * dD);
             GemmA A{w.xn.as<half_t>(), D};
@@ -363,6 +373,7 @@ void Model::encoder_from_mel_t(int n) {
             e.bias = b.mlp0_b; e.act = 1; e.c = w.h.p; e.ldc = 4 * D;
             launch_gemm_f16(A, b.mlp0_w, M, 4 * D, D, e, stream);
         }
+        WRS_DBG_STEP();
         {
             Timed tm(timer, "enc_gemm_mlp2", stream, 0, 2.0 * dM * 4 * dD * dD);
             GemmA A{w.h.as<half_t>(), 4 * (int64_t)D};
@@ -370,6 +381,7 @@ void Model::encoder_from_mel_t(int n) {
             e.bias = b.mlp2_b; e.residual = w.x.as<float>(); e.c = w.x.p; e.c_f32 = 1; e.ldc = D;
             launch_gemm_f16(A, b.mlp2_w, M, D, 4 * D, e, stream);
         }
+        WRS_DBG_STEP();
     }
     {
         Timed tm(timer, "enc_ln", stream, dM * dD * 10);

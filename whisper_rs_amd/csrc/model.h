@@ -94,6 +94,7 @@ struct Model {
     EncoderWorkspace enc_ws;
     std::unique_ptr<DecState> stage_state;  // used by the stage API (wrs_decoder_forward)
     StageTimer* timer = nullptr;            // optional per-kernel timing sink
+    int debug_enc_stop = 0;                 // debug: stop the encoder after N launches
 
     ~Model();
     void set_tensor(const std::string& name, int dtype, const int64_t* shape, int ndim, const void* data, int mem_kind);
