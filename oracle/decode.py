@@ -130,32 +130,8 @@ class BeamSearchTokenExtractor:
         if self.finished_sequences is None:
             self.finished_sequences = [dict() for _ in range(n_audio)]  # insertion-ordered
         logprobs = logits.log_softmax(dim=-1, dtype=torch.float32)  # :37
-        next_tokens, source_indices, finished_all = [], [], []
-        prefixes = tokens.tolist()
-        for i in range(n_audio):
-            cand = {}  # sequence tuple -> [score(f64), source]; first-insertion order, overwrite in place (:77)
-            for j in range(self.beam_size):
-                idx = i * self.beam_size + j
-                prefix = tuple(prefixes[idx])
-                lp, tk = logprobs[idx].topk(self.beam_size + 1, dim=-1, largest=True, sorted=True)  # :62-65
-                base = float(sum_logprobs[idx])  # double_value of the f32 tensor (:71)
-                for c in range(lp.shape[0]):
-                    seq = prefix + (int(tk[c]),)
-                    cand[seq] = [base + float(lp[c]), idx]
-            order = sorted(cand.items(), key=lambda kv: -kv[1][0])  # stable, score descending (:86)
-            finished = {}
-            saved = 0
-            for seq, (score, source) in order:  # :87-104
-                if seq[-1] == self.eot:
-                    finished[seq] = score
-                else:
-                    sum_logprobs[len(next_tokens)] = score  # stored as f32 (:91-95)
-                    next_tokens.append(list(seq))
-                    source_indices.append(source)
-                    saved += 1
-                    if saved == self.beam_size:
-                        break
-            finished_all.append(finished)
+        lp, tk = logprobs.topk(self.beam_size + 1, dim=-1, largest=True, sorted=True)  # :62-65 (per row)
+        next_tokens, source_indices, finished_all = beam_select(tokens.tolist(), sum_logprobs, lp, tk, self.beam_size, self.eot)
         new_tokens = torch.tensor(next_tokens, dtype=torch.int64)  # :109
         src = torch.tensor(source_indices, dtype=torch.int64)
         if model is not None:
@@ -183,6 +159,40 @@ class BeamSearchTokenExtractor:
         toks = [[torch.tensor(s, dtype=torch.int64) for s in seqs.keys()] for seqs in self.finished_sequences]
         lps = [list(seqs.values()) for seqs in self.finished_sequences]
         return toks, lps
+
+
+def beam_select(prefixes, sum_logprobs, cand_lp, cand_tk, beam_size, eot):
+    """STEP 1 + STEP 2 of BeamSearchTokenExtractor::update (beam_search.rs:49-107) given each row's sorted
+    top-(beam+1) candidates.  Mutates sum_logprobs in place like the reference (:91-95).
+    Returns (next_tokens, source_indices, finished_per_audio)."""
+    n_audio = len(prefixes) // beam_size
+    next_tokens, source_indices, finished_all = [], [], []
+    for i in range(n_audio):
+        cand = {}  # sequence tuple -> [score(f64), source]; first-insertion order, overwrite in place (:77)
+        for j in range(beam_size):
+            idx = i * beam_size + j
+            prefix = tuple(prefixes[idx])
+            base = float(sum_logprobs[idx])  # double_value of the f32 tensor (:71)
+            for c in range(cand_lp.shape[1]):
+                if int(cand_tk[idx, c]) < 0:
+                    continue
+                seq = prefix + (int(cand_tk[idx, c]),)
+                cand[seq] = [base + float(cand_lp[idx, c]), idx]
+        order = sorted(cand.items(), key=lambda kv: -kv[1][0])  # stable, score descending (:86)
+        finished = {}
+        saved = 0
+        for seq, (score, source) in order:  # :87-104
+            if seq[-1] == eot:
+                finished[seq] = score
+            else:
+                sum_logprobs[len(next_tokens)] = score  # stored as f32 (:91-95)
+                next_tokens.append(list(seq))
+                source_indices.append(source)
+                saved += 1
+                if saved == beam_size:
+                    break
+        finished_all.append(finished)
+    return next_tokens, source_indices, finished_all
 
 
 class GreedyTokenExtractor:

@@ -3,9 +3,11 @@ fused filters, beam search / greedy, ranking — vs the CPU oracle on identical 
 
 Bar: token ids and beam source indices bit-exact at every step; sum_logprobs within LP_TOL.
 fp16 activations perturb logits by ~1e-3 relative, so on synthetic (random-weight) models two beam
-candidates can be closer than that; when the traces split, the test requires the split to be such a
-near-tie (the per-audio sorted beam scores of both sides still agree within LP_TOL at the split step)
-and to come after MIN_EXACT_STEPS exact steps.  Anything else fails."""
+candidates can occasionally be closer than that.  If the traces split, the split must be such a
+near-tie: at the split step the per-audio sorted beam scores of both sides still agree within
+LP_TOL (i.e. the two sides only disagree about the order / identity of candidates whose scores are
+indistinguishable at this precision).  Anything else fails.  EXPECT_EXACT lists the cases that are
+required to run to the end with no split at all."""
 import numpy as np
 import pytest
 import torch
@@ -15,8 +17,7 @@ from whisper_rs_amd.consts import MODEL_DIMS, TokenIds
 from oracle import decode as OD
 
 pytestmark = pytest.mark.gpu
-LP_TOL = 5e-2       # absolute, on cumulative log-probs of magnitude ~1e1..1e3
-MIN_EXACT_STEPS = 6
+LP_TOL = 2e-2       # absolute, on cumulative log-probs of magnitude ~1e1..1e3
 
 
 def _oracle_run(dims_name, mel, oopts, prompt=None, **wkw):
@@ -47,7 +48,6 @@ def _compare(gouts, gtrace, oouts, otrace, group):
             assert abs(g.avg_logprob - o.avg_logprob) < LP_TOL / max(1, len(g.tokens))  + 1e-3
             assert abs(g.no_speech_prob - o.no_speech_prob) < 1e-4 + 0.02 * o.no_speech_prob
         return None
-    assert split >= MIN_EXACT_STEPS, f"traces split at step {split} (< {MIN_EXACT_STEPS}): not explainable by fp16 near-ties"
     R = gt.shape[1]
     for a in range(R // group):
         sl = slice(a * group, (a + 1) * group)
@@ -154,3 +154,68 @@ def test_capacity_and_errors(gpu):
     task.close()
     with pytest.raises(gpu.WrsError):
         gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(token_extract_mode=gpu.TokenExtractMode.BeamSearch(9, 1.0)))
+
+
+# ------------------------------------------------------------------------------------------------
+# Teacher-forced verification: the device follows the ORACLE's beam decisions, so every step of a
+# long decode is checked even after a near-tie (a free-running comparison ends at the first one).
+CAND_TOL = 1e-2   # |device log-prob - oracle log-prob| for every candidate the device proposes
+
+
+def _teacher_forced_check(gpu, dims_name, n_audio, sample_len, min_exact_frac, **wkw):
+    mel = mel_windows(n_audio)
+    om = oracle_model(dims_name, **wkw)
+    ot = OD.DecodeTask(om, oracle_ids(MODEL_DIMS[dims_name].n_vocab), oracle_decode_options(sample_len=sample_len, beam_size=5))
+    ot.logits_trace = []
+    oouts = ot.run_batch(torch.from_numpy(mel))
+    tr = ot.extractor.trace
+    steps, G = len(tr), 5
+    R = n_audio * G
+    ftok = np.stack([t[0].numpy() for t in tr]).astype(np.int32)
+    fsrc = np.stack([t[1].numpy() for t in tr]).astype(np.int32)
+    gm = gpu_model(gpu, dims_name, **wkw)
+    task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=sample_len, max_audio=n_audio))
+    glp, gid, gns = task.run_forced(mel, ftok, fsrc)
+    task.close()
+    ids = oracle_ids()
+    rows = [[ids.sot] for _ in range(R)]
+    slp = torch.zeros(R)
+    exact, worst = 0, 0.0
+    for s in range(steps):
+        olp_full = ot.logits_trace[s].log_softmax(-1, dtype=torch.float32)
+        # (A) every candidate the device proposes has the oracle's log-prob within CAND_TOL
+        for r in range(R):
+            for c in range(G + 1):
+                t = int(gid[s, r, c])
+                if t < 0:
+                    continue
+                d = abs(float(glp[s, r, c]) - float(olp_full[r, t]))
+                worst = max(worst, d)
+                assert d < CAND_TOL, f"step {s} row {r}: candidate {t} log-prob {glp[s, r, c]} vs oracle {float(olp_full[r, t])}"
+        # (B) the selection the reference algorithm makes from the device's candidates, starting from the oracle's state
+        work = slp.clone()
+        nt, src, _ = OD.beam_select(rows, work, torch.from_numpy(glp[s]), torch.from_numpy(gid[s].astype(np.int64)), G, ids.eot)
+        sel_tok = np.array([t[-1] for t in nt])
+        if np.array_equal(sel_tok, ftok[s]) and np.array_equal(np.array(src), fsrc[s]):
+            exact += 1
+        else:  # must be a near-tie: same sorted beam scores per audio within LP_TOL
+            for a in range(n_audio):
+                sl = slice(a * G, (a + 1) * G)
+                d = np.abs(np.sort(work[sl].numpy()) - np.sort(tr[s][2][sl].numpy())).max()
+                assert d < LP_TOL, f"step {s} audio {a}: selection differs and scores differ by {d}"
+        rows = [rows[fsrc[s][r]] + [int(ftok[s][r])] for r in range(R)]
+        slp = tr[s][2].clone()
+    for a in range(n_audio):
+        assert abs(gns[a] - oouts[a].no_speech_prob) < 1e-4 + 0.02 * oouts[a].no_speech_prob
+    print(f"{dims_name} x{n_audio}: {steps} steps teacher-forced, {exact} exact selections, worst candidate log-prob error {worst:.2e}")
+    assert exact >= min_exact_frac * steps, f"only {exact}/{steps} steps reproduced the oracle's selection exactly"
+    return exact, steps
+
+
+@pytest.mark.parametrize("dims_name,n_audio,sample_len", [("micro", 2, 48), ("tiny.en", 2, 32)])
+def test_teacher_forced_steps_vs_oracle(gpu, dims_name, n_audio, sample_len):
+    _teacher_forced_check(gpu, dims_name, n_audio, sample_len, 0.85)
+
+
+def test_teacher_forced_with_early_eot(gpu):
+    _teacher_forced_check(gpu, "micro", 2, 40, 0.8, force_eot_after=12)

@@ -295,6 +295,26 @@ class DecodeTask:
                                           _ptr(ids), _ptr(filt) if want_filtered else None))
         return (lp, ids, filt) if want_filtered else (lp, ids)
 
+    def run_forced(self, mel, forced_tokens, forced_sources):
+        """test hook (wrs_debug_decode_forced): follow the given per-step beam decisions [steps, rows] and return the
+        device's raw per-step candidates (logprobs [steps, rows, k], ids [steps, rows, k], no_speech [n_audio])."""
+        mel = _f32(mel)
+        if mel.ndim == 2:
+            mel = mel[None]
+        ft = np.ascontiguousarray(forced_tokens, dtype=np.int32)
+        fs = np.ascontiguousarray(forced_sources, dtype=np.int32)
+        steps, rows = ft.shape
+        m = self.options.token_extract_mode
+        k = m.beam_size + 1 if m.kind == "beam_search" else 1
+        lp = np.empty((steps, rows, k), np.float32)
+        ids = np.empty((steps, rows, k), np.int32)
+        ns = np.empty(mel.shape[0], np.float64)
+        fn = self._lib.wrs_debug_decode_forced
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.check(fn(self._h, _ptr(mel), mel.shape[0], steps, _ptr(ft), _ptr(fs), _ptr(lp), _ptr(ids), _ptr(ns)))
+        return lp, ids, ns
+
     def set_profiling(self, enabled: bool):
         L.check(self._lib.wrs_decode_task_set_profiling(self._h, int(enabled)))
 

@@ -333,6 +333,17 @@ void wrs_transcribe_task_destroy(wrs_transcribe_task* t) {
 }
 
 // ------------------------------------------------------------------ debug hooks (not part of wrs.h)
+// teacher-forced decode of mel [n_audio,80,3000] (host): see DecodeTask::run_forced
+int wrs_debug_decode_forced(wrs_decode_task* t, const float* mel, int n_audio, int n_steps, const int32_t* ftok, const int32_t* fsrc,
+                            float* out_lp, int32_t* out_id, double* out_no_speech) {
+    return guarded([&] {
+        WRS_REQUIRE(t && mel, "null argument");
+        Model& m = *t->t.m;
+        m.use();
+        m.load_mel(mel, n_audio, WRS_MEM_HOST, WRS_N_FRAMES, 0);
+        t->t.run_forced(n_audio, n_steps, ftok, fsrc, out_lp, out_id, out_no_speech);
+    });
+}
 int wrs_debug_set_encoder_stop(wrs_model* h, int n_launches) { if (h) h->m.debug_enc_stop = n_launches; return 0; }
 // copy an internal encoder workspace buffer to host as f32. which: 0 x(f32) 1 xn 2 qkv 3 att 4 h 5 c1 6 mel_t 7 xa16
 int wrs_debug_read_encoder(wrs_model* h, int which, float* out, int64_t n) {

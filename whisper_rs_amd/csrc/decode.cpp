@@ -289,6 +289,9 @@ void DecodeTask::run_encoded(int n_audio, wrs_decode_result* out) {
             HIP_CHECK(hipStreamSynchronize(s));
             if (p == sot_idx)
                 for (int a = 0; a < n_audio; ++a) no_speech[a] = (double)st.no_speech_h()[a];  // decode/mod.rs:250-255
+        } else {
+            // the pinned step-parameter block is rewritten for the next position: its async H2D copy must have run
+            HIP_CHECK(hipStreamSynchronize(s));
         }
     }
     if (m->timer && m->timer->enabled) { HIP_CHECK(hipStreamSynchronize(s)); m->timer->collect(); }
@@ -317,6 +320,73 @@ void DecodeTask::run_encoded(int n_audio, wrs_decode_result* out) {
     }
     finalize(n_audio, out);
     out->n_steps = n_steps;
+}
+
+// Teacher-forced run (test hook).  Step s uses forced tokens/sources [s][R] as the outcome of step s; the
+// candidates the device produced for step s (before that outcome is applied) are returned in out_lp/out_id
+// [n_steps][R][k].  Step 0 candidates come from the per-audio prefill row, replicated over its beams.
+void DecodeTask::run_forced(int n_audio, int n_steps, const int32_t* ftok, const int32_t* fsrc, float* out_lp,
+                            int32_t* out_id, double* out_no_speech) {
+    WRS_REQUIRE(n_audio >= 1 && n_audio <= max_audio && n_steps >= 1 && ftok && fsrc && out_lp && out_id, "run_forced: bad argument");
+    m->use();
+    m->encoder_from_mel_t(n_audio);
+    const int G = group, R = n_audio * G, S = sample_begin;
+    const int k = (mode == WRS_EXTRACT_BEAM_SEARCH) ? G + 1 : 1;
+    WRS_REQUIRE(S + n_steps - 1 <= m->n_ctx, "run_forced: %d prompt + %d steps exceed n_text_ctxs", S, n_steps);
+    hipStream_t s = m->stream;
+    m->load_cross_kv(st, m->enc_ws.xa16.as<half_t>(), n_audio);
+    launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m->n_ctx, m->n_ctx, st.r_cap, G, s);
+    const FilterCfg cfg = filter_cfg();
+    rows.assign(R, initial_tokens);
+    for (int p = 0; p < S; ++p) {
+        StepParams* sp = st.sp_h();
+        sp->cache_pos = p; sp->pos_idx = p; sp->parity = 0; sp->first_step = 1;
+        sp->want_no_speech = (p == sot_idx) ? 1 : 0; sp->n_rows = n_audio;
+        for (int a = 0; a < n_audio; ++a) { st.tokens_h()[a] = (int)initial_tokens[p]; st.src_h()[a] = a; st.tsmode_h()[a] = 0; }
+        upload_step(n_audio);
+        const bool want_logits = (p == S - 1) || p == sot_idx;
+        m->decoder_step(st, n_audio, G, 1, false, want_logits);
+        if (want_logits)
+            launch_filter_topk(st.logits.as<float>(), n_audio, cfg, st.sp_d(), st.tsmode_d(), k, st.topk_lp_d(), st.topk_id_d(),
+                               st.no_speech_d(), nullptr, s);
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (p == sot_idx && out_no_speech)
+            for (int a = 0; a < n_audio; ++a) out_no_speech[a] = (double)st.no_speech_h()[a];
+    }
+    for (int r = 0; r < R; ++r)
+        for (int c = 0; c < k; ++c) {
+            out_lp[(size_t)r * k + c] = st.topk_lp()[(r / G) * k + c];
+            out_id[(size_t)r * k + c] = st.topk_id()[(r / G) * k + c];
+        }
+    auto apply = [&](int step) {
+        std::vector<std::vector<int64_t>> nr(R);
+        for (int r = 0; r < R; ++r) {
+            const int src = fsrc[(size_t)step * R + r];
+            WRS_REQUIRE(src >= 0 && src < R, "run_forced: source %d out of range", src);
+            nr[r] = rows[src];
+            nr[r].push_back(ftok[(size_t)step * R + r]);
+        }
+        rows.swap(nr);
+        sources.assign(fsrc + (size_t)step * R, fsrc + (size_t)(step + 1) * R);
+    };
+    sources.assign(R, 0);
+    apply(0);
+    for (int i = 1; i < n_steps; ++i) {
+        StepParams* sp = st.sp_h();
+        sp->cache_pos = S + i - 1;
+        sp->pos_idx = position_quirk ? i : S + i - 1;
+        sp->parity = i & 1; sp->first_step = 0; sp->want_no_speech = 0; sp->n_rows = R;
+        for (int r = 0; r < R; ++r) {
+            WRS_REQUIRE(rows[r].back() >= 0 && rows[r].back() < m->V, "run_forced: token out of range");
+            st.tokens_h()[r] = (int)rows[r].back();
+            st.src_h()[r] = sources[r];
+            st.tsmode_h()[r] = timestamps ? ts_mode_of(rows[r], S, ids.ts_begin) : 0;
+        }
+        step_decode(R);
+        memcpy(out_lp + (size_t)i * R * k, st.topk_lp(), (size_t)R * k * 4);
+        memcpy(out_id + (size_t)i * R * k, st.topk_id(), (size_t)R * k * 4);
+        apply(i);
+    }
 }
 
 // finalize (beam_search.rs:151-206 / greedy.rs:54-58), slice [sample_begin, first EOT) (decode/mod.rs:356-370),

@@ -62,6 +62,10 @@ struct DecodeTask {
     void run_loaded(int n_audio, wrs_decode_result* out);
     // encoder output already in m->enc_ws.xa16/xa32
     void run_encoded(int n_audio, wrs_decode_result* out);
+    // test hook: follow externally given beam decisions (tokens/sources per step) and return the device's raw
+    // per-step top-k candidates; the window batch must already be in m->enc_ws.mel_t
+    void run_forced(int n_audio, int n_steps, const int32_t* ftok, const int32_t* fsrc, float* out_lp, int32_t* out_id,
+                    double* out_no_speech);
 
     void upload_step(int rows_n);
     void step_decode(int rows_n);  // decoder_step + filter_topk for rows_n = n_audio*group rows (graph-replayed)
