@@ -255,6 +255,12 @@ typedef struct wrs_stage_time {
     double flops;       /* algorithmic flops, summed over launches */
 } wrs_stage_time;
 int wrs_decode_task_set_profiling(wrs_decode_task* t, int enabled);
+/* live timing of the dominant decode kernel (cross-attention, HBM-bound) with HIP events on the library's
+ * stream during normal runs: every 16th decode step is launched eagerly instead of from the captured graph,
+ * with an event pair around the kernel in every `layer_stride`-th layer.  get: summed ms, launches and
+ * algorithmic bytes (n_audio * 2 * 1500 * D * 2 B per launch) since the last set. */
+int wrs_decode_task_set_cross_timing(wrs_decode_task* t, int enabled, int layer_stride);
+int wrs_decode_task_get_cross_timing(wrs_decode_task* t, double* ms, int64_t* launches, double* bytes);
 int wrs_decode_task_stage_times(wrs_decode_task* t, wrs_stage_time* out, int32_t cap, int32_t* n);
 
 #ifdef __cplusplus

@@ -318,6 +318,14 @@ class DecodeTask:
     def set_profiling(self, enabled: bool):
         L.check(self._lib.wrs_decode_task_set_profiling(self._h, int(enabled)))
 
+    def set_cross_timing(self, enabled: bool, layer_stride: int = 8):
+        L.check(self._lib.wrs_decode_task_set_cross_timing(self._h, int(enabled), layer_stride))
+
+    def cross_timing(self):
+        ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+        L.check(self._lib.wrs_decode_task_get_cross_timing(self._h, C.byref(ms), C.byref(n), C.byref(b)))
+        return dict(ms=ms.value, launches=n.value, bytes=b.value)
+
     def stage_times(self):
         n = C.c_int32()
         buf = (L.StageTimeC * 64)()

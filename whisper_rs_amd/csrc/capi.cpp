@@ -363,6 +363,26 @@ int wrs_debug_read_encoder(wrs_model* h, int which, float* out, int64_t n) {
 }
 
 // ------------------------------------------------------------------ measurement
+// live, sampled HIP-event timing of the cross-attention decode kernel inside the replayed step graph
+int wrs_decode_task_set_cross_timing(wrs_decode_task* t, int enabled, int layer_stride) {
+    return guarded([&] {
+        WRS_REQUIRE(t && layer_stride >= 1, "bad argument");
+        Model& m = *t->t.m;
+        HIP_CHECK(hipStreamSynchronize(m.stream));
+        m.cross_ev_enabled = enabled != 0;
+        m.cross_ev_stride = layer_stride;
+        m.cross_ev_step = 0;
+        m.cross_ev_ms = 0; m.cross_ev_launches = 0; m.cross_ev_bytes = 0;
+    });
+}
+int wrs_decode_task_get_cross_timing(wrs_decode_task* t, double* ms, int64_t* launches, double* bytes) {
+    return guarded([&] {
+        WRS_REQUIRE(t && ms && launches && bytes, "bad argument");
+        Model& m = *t->t.m;
+        *ms = m.cross_ev_ms; *launches = m.cross_ev_launches; *bytes = m.cross_ev_bytes;
+    });
+}
+
 int wrs_decode_task_set_profiling(wrs_decode_task* t, int enabled) {
     return guarded([&] {
         WRS_REQUIRE(t, "null task");

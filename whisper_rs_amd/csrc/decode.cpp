@@ -116,7 +116,8 @@ void DecodeTask::step_decode(int R) {
                            st.no_speech_d(), nullptr, m->stream);
     };
     const bool profiling = m->timer && m->timer->enabled;
-    if (use_graph && !profiling) {
+    const bool sample_now = m->cross_ev_enabled && (m->cross_ev_step++ % m->cross_ev_every == 0);
+    if (use_graph && !profiling && !sample_now) {
         if (!graph_exec || graph_rows != R) {
             if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
             if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
@@ -134,10 +135,14 @@ void DecodeTask::step_decode(int R) {
             graph_rows = R;
         }
         HIP_CHECK(hipGraphLaunch(graph_exec, m->stream));
+        HIP_CHECK(hipStreamSynchronize(m->stream));
     } else {
+        m->cross_ev_now = sample_now;
         body();
+        HIP_CHECK(hipStreamSynchronize(m->stream));
+        m->collect_cross_events(R / group);
+        m->cross_ev_now = false;
     }
-    HIP_CHECK(hipStreamSynchronize(m->stream));
 }
 
 void DecodeTask::record_trace(int R) {

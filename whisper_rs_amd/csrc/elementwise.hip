@@ -191,43 +191,73 @@ void launch_layernorm(const float* x, const float* g, const float* b, int64_t M,
 // decode step: x[m] += bias + sum_s slab[s][m] (fixed order => deterministic), then xn = LN(x).
 // Fuses the split-K reduction of the out-projection / MLP-2 GEMM, the residual add
 // (reference model.rs:302-318) and the next LayerNorm into one pass over [M, D].
-template <int NV>
+// One 256-thread workgroup per row (the step has only <= 320 rows: parallelism comes from splitting
+// the row, and all ksplit slab loads of a thread are independent and in flight together).
+template <int NV>  // float4 vectors per thread: D <= 1024 * NV
 __global__ __launch_bounds__(256) void finish_residual_ln_kernel(float* __restrict__ x, const float* __restrict__ slab,
                                                                  int ksplit, int m_pad, const float* __restrict__ bias,
                                                                  const float* __restrict__ g, const float* __restrict__ b,
                                                                  int M, int D, half_t* __restrict__ xn) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x;
     floatx4 v[NV];
+    float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
+        const int c = (i * 256 + tid) * 4;
+        v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
         if (c < D) {
-            floatx4 a = *reinterpret_cast<const floatx4*>(x + (int64_t)row * D + c);
             floatx4 acc = *reinterpret_cast<const floatx4*>(slab + (int64_t)row * D + c);
             for (int sidx = 1; sidx < ksplit; ++sidx)
                 acc += *reinterpret_cast<const floatx4*>(slab + ((int64_t)sidx * m_pad + row) * D + c);
             if (bias) acc += *reinterpret_cast<const floatx4*>(bias + c);
-            a += acc;
+            const floatx4 a = *reinterpret_cast<const floatx4*>(x + (int64_t)row * D + c) + acc;
             *reinterpret_cast<floatx4*>(x + (int64_t)row * D + c) = a;
             v[i] = a;
-        } else {
-            v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+            s += (a[0] + a[1]) + (a[2] + a[3]);
         }
     }
-    if (xn) ln_row<NV>(v, D, lane, g, b, xn + (int64_t)row * D, nullptr);
+    if (!xn) return;
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 256 + tid) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = v[i][r] - mean;
+                q += d * d;
+            }
+        }
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 256 + tid) * 4;
+        if (c < D) {
+            const floatx4 gg = *reinterpret_cast<const floatx4*>(g + c);
+            const floatx4 bb = *reinterpret_cast<const floatx4*>(b + c);
+            half4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (_Float16)((v[i][r] - mean) * rstd * gg[r] + bb[r]);
+            *reinterpret_cast<half4*>(xn + (int64_t)row * D + c) = y;
+        }
+    }
 }
 
 void launch_finish_residual_ln(float* x, const float* slab, int ksplit, int m_pad, const float* bias, const float* g,
                                const float* b, int M, int D, half_t* xn, hipStream_t s) {
-    const unsigned grid = (unsigned)cdiv(M, 4);
-    switch (ln_nv(D)) {
-#define WRS_FIN(NV) case NV: finish_residual_ln_kernel<NV><<<grid, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn); break;
-        WRS_FIN(1) WRS_FIN(2) WRS_FIN(3) WRS_FIN(4) WRS_FIN(5)
-#undef WRS_FIN
-        default: finish_residual_ln_kernel<8><<<grid, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn); break;
-    }
+    WRS_REQUIRE(D % 4 == 0 && D <= 2048, "finish_residual_ln: D=%d unsupported", D);
+    if (D <= 1024) finish_residual_ln_kernel<1><<<M, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
+    else finish_residual_ln_kernel<2><<<M, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
 }
 
 // reference model.rs:503-506: token_emb(tokens) + position_emb[offset..]; fused with the first block's attn_ln.

@@ -263,6 +263,11 @@ int skinny_m_pad(int M) {
     return -1;
 }
 
+// Per wave: up to SK_NKS k-steps (the launcher picks ksplit accordingly).  All weight fragments of the
+// wave (the HBM stream, ~1-2 us latency) are requested up front; activation fragments (L2-resident,
+// shared by every workgroup) are double-buffered one k-step ahead.  The k-loop is fully unrolled so the
+// compiler can keep every load in flight behind the MFMAs.
+#define SK_NKS 10
 template <int MT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) {
     __shared__ float red[4][MT][4][64];
@@ -280,17 +285,35 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
     const half_t* w1 = p.wp + ((int64_t)(blockIdx.x * 2 + 1) * p.ksteps) * 512 + lane * 8;
     const half_t* ab = p.a + (int64_t)(lane & 15) * p.K + (lane >> 4) * 8;
 
-    for (int ks = ks_begin + wave; ks < ks_end; ks += 4) {
-        const half8 f0 = *reinterpret_cast<const half8*>(w0 + (int64_t)ks * 512);
-        const half8 f1 = *reinterpret_cast<const half8*>(w1 + (int64_t)ks * 512);
-        half8 af[MT];
+    half8 wf0[SK_NKS], wf1[SK_NKS];
+#pragma unroll
+    for (int i = 0; i < SK_NKS; ++i) {
+        const int ks = ks_begin + wave + 4 * i;
+        if (ks < ks_end) {
+            wf0[i] = *reinterpret_cast<const half8*>(w0 + (int64_t)ks * 512);
+            wf1[i] = *reinterpret_cast<const half8*>(w1 + (int64_t)ks * 512);
+        }
+    }
+    half8 af[2][MT];
+    if (ks_begin + wave < ks_end) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-            af[mt] = *reinterpret_cast<const half8*>(ab + (int64_t)mt * 16 * p.K + ks * 32);
+            af[0][mt] = *reinterpret_cast<const half8*>(ab + (int64_t)mt * 16 * p.K + (ks_begin + wave) * 32);
+    }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, af[mt], acc[0][mt], 0, 0, 0);
-            acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, af[mt], acc[1][mt], 0, 0, 0);
+    for (int i = 0; i < SK_NKS; ++i) {
+        const int ks = ks_begin + wave + 4 * i;
+        if (ks < ks_end) {
+            if (i + 1 < SK_NKS && ks + 4 < ks_end) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    af[(i + 1) & 1][mt] = *reinterpret_cast<const half8*>(ab + (int64_t)mt * 16 * p.K + (ks + 4) * 32);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[i], af[i & 1][mt], acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[i], af[i & 1][mt], acc[1][mt], 0, 0, 0);
+            }
         }
     }
 
@@ -361,6 +384,7 @@ void launch_gemm_skinny(const half_t* a, const half_t* w_packed, int M, int64_t 
                 (long)n_pad, (long)K);
     WRS_REQUIRE(ksplit >= 1 && (K / 32) % ksplit == 0, "gemm_skinny: ksplit %d does not divide K/32=%ld", ksplit, (long)(K / 32));
     WRS_REQUIRE(ksplit == 1 || e.kind == SK_SLAB, "gemm_skinny: split-K needs the slab epilogue");
+    WRS_REQUIRE(cdiv(K / 32 / ksplit, 4) <= SK_NKS, "gemm_skinny: K=%ld with ksplit %d exceeds %d k-steps per wave", (long)K, ksplit, SK_NKS);
     if (e.kind == SK_F16 || e.kind == SK_QKV_SELF || e.kind == SK_SLAB)
         WRS_REQUIRE(N % 4 == 0 && (e.kind == SK_SLAB || e.ldc % 4 == 0), "gemm_skinny: N and ldc must be multiples of 4");
     if (e.kind == SK_QKV_SELF)

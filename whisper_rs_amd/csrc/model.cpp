@@ -55,8 +55,21 @@ void StageTimer::reset() {
 
 // ------------------------------------------------------------------------------------------ model
 Model::~Model() {
+    for (auto e : cross_ev) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
     delete timer;
+}
+
+void Model::collect_cross_events(int n_audio) {
+    if (!cross_ev_now) return;
+    for (size_t i = 0; i + 1 < cross_ev.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, cross_ev[i], cross_ev[i + 1]) == hipSuccess) {
+            cross_ev_ms += ms;
+            cross_ev_launches += 1;
+            cross_ev_bytes += (double)n_audio * 2.0 * T * D * 2.0;  // K and V of every audio, fp16, once per launch
+        }
+    }
 }
 
 void Model::use() const { HIP_CHECK(hipSetDevice(device)); }
@@ -444,11 +457,13 @@ void Model::load_cross_kv(DecState& st, const half_t* xa16, int n_audio) {
     st.n_audio = n_audio;
 }
 
+// split-K factor of a slab GEMM: enough workgroups (N/32 * ksplit) to spread the weight stream over the
+// chip, and at most 10 k-steps per wave so every weight fragment is requested up front (gemm.hip SK_NKS)
 static int pick_ksplit(int64_t N, int64_t K, int cap) {
     const int ksteps = (int)(K / 32);
     const int wgs = (int)(N / 32);
     int ks = 1;
-    while (ks * 2 <= cap && wgs * ks * 2 <= 512 && ksteps % (ks * 2) == 0 && ksteps / (ks * 2) >= 4) ks *= 2;
+    while (ks * 2 <= cap && ksteps % (ks * 2) == 0 && (ksteps / ks > 40 || (wgs * ks < 160 && ksteps / (ks * 2) >= 8))) ks *= 2;
     return ks;
 }
 
@@ -508,8 +523,15 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
         }
         {
             Timed tm(timer, "dec_attn_cross", stream, (double)n_audio * 2.0 * T * D * 2.0);
+            const bool sample = cross_ev_now && (l % cross_ev_stride == 0);
+            const int slot = l / cross_ev_stride;
+            if (sample) {
+                while ((int)cross_ev.size() < 2 * (slot + 1)) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); cross_ev.push_back(e); }
+                HIP_CHECK(hipEventRecord(cross_ev[2 * slot], stream));
+            }
             launch_attn_cross(st.q.as<half_t>(), D, st.cross_kp.as<half_t>() + l * cross_layer,
                               st.cross_vp.as<half_t>() + l * cross_layer, n_audio, q_per_audio, T, H, st.att.as<half_t>(), D, stream);
+            if (sample) HIP_CHECK(hipEventRecord(cross_ev[2 * slot + 1], stream));
         }
         {
             Timed tm(timer, "dec_gemm_out", stream, wD);

@@ -95,6 +95,19 @@ struct Model {
     std::unique_ptr<DecState> stage_state;  // used by the stage API (wrs_decoder_forward)
     StageTimer* timer = nullptr;            // optional per-kernel timing sink
     int debug_enc_stop = 0;                 // debug: stop the encoder after N launches
+    // live timing of the dominant decode kernel (cross-attention) with HIP events on this stream: every
+    // `cross_ev_every`-th decode step is launched eagerly (not from the graph) with event pairs around the
+    // kernel in every `cross_ev_stride`-th layer; all other steps replay the captured graph untouched
+    bool cross_ev_enabled = false;
+    bool cross_ev_now = false;
+    int cross_ev_stride = 8;
+    int cross_ev_every = 16;
+    int64_t cross_ev_step = 0;
+    std::vector<hipEvent_t> cross_ev;       // 2 per sampled layer
+    double cross_ev_ms = 0;
+    int64_t cross_ev_launches = 0;
+    double cross_ev_bytes = 0;
+    void collect_cross_events(int n_audio);
 
     ~Model();
     void set_tensor(const std::string& name, int dtype, const int64_t* shape, int ndim, const void* data, int mem_kind);
