@@ -147,6 +147,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     cross = task.cross_timing()
+    split = task.last_run_times()
     task.set_cross_timing(False, args.cross_stride)
     n_steps_decoded = task.n_steps
     if world > 1:
@@ -190,6 +191,7 @@ def main():
                                    f"mel+encoder+decoder+beam search end to end, random-init weights",
                        "windows_per_step_per_gpu": args.batch, "beam": args.beam, "sample_len": args.sample_len, "sharding": f"windows x{world}, no collective"},
             "roofline": rl,
+            "last_step_split_ms": {k: round(v, 2) for k, v in split.items()},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(dims, args.beam, args.sample_len)

@@ -255,6 +255,9 @@ typedef struct wrs_stage_time {
     double flops;       /* algorithmic flops, summed over launches */
 } wrs_stage_time;
 int wrs_decode_task_set_profiling(wrs_decode_task* t, int enabled);
+/* host wall-clock split of the last wrs_decode_task_run* call (ms): mel+encoder+cross-K/V (to the first sync),
+ * prompt prefill, device decode steps (launch + wait), host sequencer (beam search, parameter upload prep). */
+int wrs_decode_task_last_run_times(wrs_decode_task* t, double* encoder_ms, double* prefill_ms, double* steps_ms, double* host_ms);
 /* live timing of the dominant decode kernel (cross-attention, HBM-bound) with HIP events on the library's
  * stream during normal runs: every 16th decode step is launched eagerly instead of from the captured graph,
  * with an event pair around the kernel in every `layer_stride`-th layer.  get: summed ms, launches and

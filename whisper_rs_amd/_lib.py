@@ -102,6 +102,7 @@ SYMBOLS = {
     "wrs_transcribe_task_destroy": (None, [C.c_void_p]),
     "wrs_decode_task_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "wrs_decode_task_stage_times": (C.c_int, [C.c_void_p, P(StageTimeC), C.c_int32, P(C.c_int32)]),
+    "wrs_decode_task_last_run_times": (C.c_int, [C.c_void_p, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double)]),
     "wrs_decode_task_set_cross_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "wrs_decode_task_get_cross_timing": (C.c_int, [C.c_void_p, P(C.c_double), P(C.c_int64), P(C.c_double)]),
 }

@@ -318,6 +318,11 @@ class DecodeTask:
     def set_profiling(self, enabled: bool):
         L.check(self._lib.wrs_decode_task_set_profiling(self._h, int(enabled)))
 
+    def last_run_times(self):
+        a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        L.check(self._lib.wrs_decode_task_last_run_times(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(encoder_ms=a.value, prefill_ms=b.value, steps_ms=c.value, host_ms=d.value)
+
     def set_cross_timing(self, enabled: bool, layer_stride: int = 8):
         L.check(self._lib.wrs_decode_task_set_cross_timing(self._h, int(enabled), layer_stride))
 

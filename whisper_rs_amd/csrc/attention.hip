@@ -89,6 +89,12 @@ struct AttnParams {
     int q_valid;           // SPLIT: number of valid query rows (G); else unused
     half_t* out;
     int64_t ldo;
+    // SPLIT only: Q = (sum_s q_slab[s][row][:] + q_bias) * q_scale, the un-reduced split-K output of the
+    // cross-attention query projection (fuses the slab reduction + bias + scale into this kernel)
+    const float* q_slab;
+    int q_ksplit, q_m_pad;
+    const float* q_bias;
+    float q_scale;
 };
 
 template <bool SPLIT>
@@ -114,7 +120,27 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (qcol < n_valid) v = *reinterpret_cast<const half8*>(p.q + (qrow0 + qcol) * p.ldq + h * 64 + ks * 32 + 8 * qg);
+        if (qcol < n_valid) {
+            if (SPLIT && p.q_slab) {
+                const int N = p.H * 64;
+                const int col = h * 64 + ks * 32 + 8 * qg;
+                const float* src = p.q_slab + (qrow0 + qcol) * N + col;
+                floatx4 a0 = *reinterpret_cast<const floatx4*>(src), a1 = *reinterpret_cast<const floatx4*>(src + 4);
+                for (int sidx = 1; sidx < p.q_ksplit; ++sidx) {
+                    a0 += *reinterpret_cast<const floatx4*>(src + (int64_t)sidx * p.q_m_pad * N);
+                    a1 += *reinterpret_cast<const floatx4*>(src + (int64_t)sidx * p.q_m_pad * N + 4);
+                }
+                a0 += *reinterpret_cast<const floatx4*>(p.q_bias + col);
+                a1 += *reinterpret_cast<const floatx4*>(p.q_bias + col + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = (_Float16)(a0[j] * p.q_scale);
+                    v[4 + j] = (_Float16)(a1[j] * p.q_scale);
+                }
+            } else {
+                v = *reinterpret_cast<const half8*>(p.q + (qrow0 + qcol) * p.ldq + h * 64 + ks * 32 + 8 * qg);
+            }
+        }
         qf[ks] = v;
     }
 
@@ -232,7 +258,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
                 for (int w = 0; w < 4; ++w) a += wgt[w] * so[w][d0 + r][qq];
                 r4[r] = a * inv;
             }
-            *reinterpret_cast<half4*>(p.out + (qrow0 + qq) * p.ldo + h * 64 + d0) =
+            // decode output feeds the out-projection GEMM: packed activation order (K = H*64)
+            *reinterpret_cast<half4*>(p.out + pa_off((int)(qrow0 + qq), h * 64 + d0, p.H * 2)) =
                 half4{(_Float16)r4[0], (_Float16)r4[1], (_Float16)r4[2], (_Float16)r4[3]};
         }
     }
@@ -241,94 +268,168 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
 void launch_attn_full(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_batch, int Tq, int T, int H,
                       half_t* out, int64_t ldo, hipStream_t s) {
     WRS_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && T >= 1 && Tq >= 1, "attn_full: bad shape");
-    AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, Tq, 0, out, ldo};
+    AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, Tq, 0, out, ldo, nullptr, 0, 0, nullptr, 1.f};
     dim3 grid((unsigned)cdiv(Tq, 64), (unsigned)H, (unsigned)n_batch);
     attn_mfma_kernel<false><<<grid, 256, 0, s>>>(p);
 }
 
-void launch_attn_cross(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_audio, int G, int T, int H,
-                       half_t* out, int64_t ldo, hipStream_t s) {
+void launch_attn_cross(const float* q_slab, int q_ksplit, int q_m_pad, const float* q_bias, float q_scale, const half_t* kp,
+                       const half_t* vp, int n_audio, int G, int T, int H, half_t* out, hipStream_t s) {
     WRS_REQUIRE(G >= 1 && G <= 16, "attn_cross: group size %d not in 1..16", G);
-    WRS_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && T >= 1, "attn_cross: bad shape");
-    AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, G, G, out, ldo};
+    WRS_REQUIRE(T >= 1 && q_slab && q_bias && q_ksplit >= 1, "attn_cross: bad argument");
+    AttnParams p{nullptr, 0, kp, vp, T, (int)round_up(T, 32), H, G, G, out, 0, q_slab, q_ksplit, q_m_pad, q_bias, q_scale};
     dim3 grid(1, (unsigned)H, (unsigned)n_audio);
     attn_mfma_kernel<true><<<grid, 256, 0, s>>>(p);
 }
 
 // ------------------------------------------------------------------------------------------ decode self-attention
-// One wave per (row, head); K/V rows come from the ancestry-indirected cache
-// kc/vc [phys_row][n_ctx][D].  Lanes = 8 position groups x 8 dim chunks (16 B each): every wave
-// load instruction fetches 8 full 128-B lines.  Length <= 448, so scores live in LDS.
-__global__ __launch_bounds__(256) void attn_self_kernel(const half_t* __restrict__ q, int64_t ldq,
-                                                        const half_t* __restrict__ kc, const half_t* __restrict__ vc,
-                                                        const int* __restrict__ anc_base, int64_t anc_buf_stride, int n_ctx,
-                                                        int n_rows, int phys_mul, int H, int D,
-                                                        const StepParams* __restrict__ sp, half_t* __restrict__ out,
-                                                        int64_t ldo) {
+// One wave per (row, head).  Fuses, for the new token: the split-K reduction of the QKV projection
+// (slabs [ksplit][m_pad][3D]) + bias + the (D/H)^-0.25 scale on q and k (reference model.rs:159-182), the
+// append of k/v to the cache (Cached::forward, model.rs:83-87) and the attention over the
+// ancestry-indirected cache kc/vc [phys_row][n_ctx][D] (Cached::update_cache, model.rs:53-62).
+// Lanes = 8 position groups x 8 dim chunks (16 B each): every wave load instruction fetches 8 full 128-B
+// lines; 4 such loads are kept in flight.  Length <= 448, so scores live in LDS.
+struct SelfAttnParams {
+    const float* slab;
+    int ksplit, m_pad;
+    const float* bias;  // [3D]
+    float scale;
+    half_t* kc;
+    half_t* vc;
+    const int* anc_base;
+    int64_t anc_buf_stride;
+    int n_ctx, n_rows, phys_mul, H, D;
+    const StepParams* sp;
+    half_t* out;  // packed activation order
+};
+
+__device__ __forceinline__ void slab_chunk8(const float* __restrict__ slab, int ksplit, int64_t slab_stride, int64_t off,
+                                            const float* __restrict__ bias, int col, float (&o)[8]) {
+    floatx4 a0 = *reinterpret_cast<const floatx4*>(slab + off), a1 = *reinterpret_cast<const floatx4*>(slab + off + 4);
+    for (int sidx = 1; sidx < ksplit; ++sidx) {
+        a0 += *reinterpret_cast<const floatx4*>(slab + sidx * slab_stride + off);
+        a1 += *reinterpret_cast<const floatx4*>(slab + sidx * slab_stride + off + 4);
+    }
+    a0 += *reinterpret_cast<const floatx4*>(bias + col);
+    a1 += *reinterpret_cast<const floatx4*>(bias + col + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o[j] = a0[j];
+        o[4 + j] = a1[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) {
     __shared__ float sc[4][512];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * 4 + wave;
-    if (unit >= n_rows * H) return;  // no block-level barriers below
-    const int row = unit / H, h = unit % H;
+    if (unit >= p.n_rows * p.H) return;  // no block-level barriers below
+    const int row = unit / p.H, h = unit % p.H;
     const int g = lane >> 3, c = lane & 7;
-    const int len = sp->cache_pos + 1;
-    const int phys = row * phys_mul;
-    const int* anc = anc_base + (int64_t)sp->parity * anc_buf_stride + (int64_t)phys * n_ctx;
-    const int64_t row_stride = (int64_t)n_ctx * D;
+    const int D = p.D;
+    const int cpos = p.sp->cache_pos;  // the new token's slot; cached positions are 0..cpos-1
+    const int phys = row * p.phys_mul;
+    const int* anc = p.anc_base + (int64_t)p.sp->parity * p.anc_buf_stride + (int64_t)phys * p.n_ctx;
+    const int64_t row_stride = (int64_t)p.n_ctx * D;
+    const int col = h * 64 + c * 8;
 
-    float qv[8];
+    // new token: q, k, v chunk c from the QKV slabs
+    float qv[8], kn[8], vn[8];
     {
-        const half8 t = *reinterpret_cast<const half8*>(q + (int64_t)row * ldq + h * 64 + c * 8);
+        const int64_t ss = (int64_t)p.m_pad * 3 * D, off = (int64_t)row * 3 * D + col;
+        slab_chunk8(p.slab, p.ksplit, ss, off, p.bias, col, qv);
+        slab_chunk8(p.slab, p.ksplit, ss, off + D, p.bias, D + col, kn);
+        slab_chunk8(p.slab, p.ksplit, ss, off + 2 * D, p.bias, 2 * D + col, vn);
+        half8 k16, v16;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qv[j] = (float)t[j];
-    }
-    float mx = -INFINITY;
-    for (int p0 = 0; p0 < len; p0 += 8) {
-        const int pos = p0 + g;
-        float s = -INFINITY;
-        if (pos < len) {
-            const int pr = anc[pos];
-            const half8 kv = *reinterpret_cast<const half8*>(kc + (int64_t)pr * row_stride + (int64_t)pos * D + h * 64 + c * 8);
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a += qv[j] * (float)kv[j];
-            s = a;
+        for (int j = 0; j < 8; ++j) {
+            qv[j] *= p.scale;
+            k16[j] = (_Float16)(kn[j] * p.scale);
+            v16[j] = (_Float16)vn[j];
+            kn[j] = (float)k16[j];  // use exactly what later steps will read back from the fp16 cache
+            vn[j] = (float)v16[j];
         }
-        // reduce the 8 dim-chunk partials (lanes differing in bits 0..2)
-        float t = (pos < len) ? s : 0.f;
-        t += __shfl_xor(t, 1);
-        t += __shfl_xor(t, 2);
-        t += __shfl_xor(t, 4);
-        if (pos < len) {
-            if (c == 0) sc[wave][pos] = t;
-            mx = fmaxf(mx, t);
+        if (g == 0) {
+            *reinterpret_cast<half8*>(p.kc + (int64_t)phys * row_stride + (int64_t)cpos * D + col) = k16;
+            *reinterpret_cast<half8*>(p.vc + (int64_t)phys * row_stride + (int64_t)cpos * D + col) = v16;
+        }
+    }
+    // score of the new position
+    float s_new = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_new += qv[j] * kn[j];
+    s_new += __shfl_xor(s_new, 1);
+    s_new += __shfl_xor(s_new, 2);
+    s_new += __shfl_xor(s_new, 4);
+    float mx = s_new;
+
+    for (int p0 = 0; p0 < cpos; p0 += 32) {
+        half8 kv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pos = p0 + u * 8 + g;
+            ok[u] = pos < cpos;
+            kv[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok[u]) {
+                const int pr = anc[pos];
+                kv[u] = *reinterpret_cast<const half8*>(p.kc + (int64_t)pr * row_stride + (int64_t)pos * D + col);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += qv[j] * (float)kv[u][j];
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 4);
+            if (ok[u]) {
+                if (c == 0) sc[wave][p0 + u * 8 + g] = t;
+                mx = fmaxf(mx, t);
+            }
         }
     }
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
+    const float e_new = __expf(s_new - mx);
     float sum = 0.f;
-    for (int pos = lane; pos < len; pos += 64) {
+    for (int pos = lane; pos < cpos; pos += 64) {
         const float e = __expf(sc[wave][pos] - mx);
         sc[wave][pos] = e;
         sum += e;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum += e_new;
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     const float inv = 1.f / sum;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int p0 = 0; p0 < len; p0 += 8) {
-        const int pos = p0 + g;
-        if (pos < len) {
-            const int pr = anc[pos];
-            const float w = sc[wave][pos];
-            const half8 vv = *reinterpret_cast<const half8*>(vc + (int64_t)pr * row_stride + (int64_t)pos * D + h * 64 + c * 8);
+    if (g == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += w * (float)vv[j];
+        for (int j = 0; j < 8; ++j) acc[j] = e_new * vn[j];
+    }
+    for (int p0 = 0; p0 < cpos; p0 += 32) {
+        half8 vv[4];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pos = p0 + u * 8 + g;
+            vv[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            w[u] = 0.f;
+            if (pos < cpos) {
+                const int pr = anc[pos];
+                w[u] = sc[wave][pos];
+                vv[u] = *reinterpret_cast<const half8*>(p.vc + (int64_t)pr * row_stride + (int64_t)pos * D + col);
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w[u] * (float)vv[u][j];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -340,16 +441,17 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const half_t* __restrict
         half8 r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = (_Float16)(acc[j] * inv);
-        *reinterpret_cast<half8*>(out + (int64_t)row * ldo + h * 64 + c * 8) = r;
+        *reinterpret_cast<half8*>(p.out + pa_off(row, col, D >> 5)) = r;  // packed activation order
     }
 }
 
-void launch_attn_self(const half_t* q, int64_t ldq, const half_t* kc, const half_t* vc, const int* anc_base,
-                      int64_t anc_buf_stride, int n_ctx, int n_rows, int phys_mul, int H, int D, const StepParams* sp,
-                      half_t* out, int64_t ldo, hipStream_t s) {
-    WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && ldq % 8 == 0 && ldo % 8 == 0, "attn_self: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
+void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc,
+                      const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, int phys_mul, int H, int D,
+                      const StepParams* sp, half_t* out, hipStream_t s) {
+    WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && qkv_slab && qkv_bias && ksplit >= 1, "attn_self: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
+    SelfAttnParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out};
     const unsigned grid = (unsigned)cdiv((int64_t)n_rows * H, 4);
-    attn_self_kernel<<<grid, 256, 0, s>>>(q, ldq, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, ldo);
+    attn_self_kernel<<<grid, 256, 0, s>>>(p);
 }
 
 }  // namespace wrs

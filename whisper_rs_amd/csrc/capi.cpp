@@ -363,6 +363,15 @@ int wrs_debug_read_encoder(wrs_model* h, int which, float* out, int64_t n) {
 }
 
 // ------------------------------------------------------------------ measurement
+int wrs_decode_task_last_run_times(wrs_decode_task* t, double* encoder_ms, double* prefill_ms, double* steps_ms, double* host_ms) {
+    return guarded([&] {
+        WRS_REQUIRE(t, "null task");
+        if (encoder_ms) *encoder_ms = t->t.t_encoder_ms;
+        if (prefill_ms) *prefill_ms = t->t.t_prefill_ms;
+        if (steps_ms) *steps_ms = t->t.t_steps_ms;
+        if (host_ms) *host_ms = t->t.t_host_ms;
+    });
+}
 // live, sampled HIP-event timing of the cross-attention decode kernel inside the replayed step graph
 int wrs_decode_task_set_cross_timing(wrs_decode_task* t, int enabled, int layer_stride) {
     return guarded([&] {

@@ -8,9 +8,14 @@
 //   admitted in that order (:131-137), final candidates are listed in admission order.
 #include "decode.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 namespace wrs {
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static double round_half_away(double x) { return x >= 0 ? std::floor(x + 0.5) : -std::floor(-x + 0.5); }
 
@@ -248,8 +253,11 @@ bool DecodeTask::update_greedy(int n_audio, bool step0) {
 void DecodeTask::run_loaded(int n_audio, wrs_decode_result* out) {
     WRS_REQUIRE(n_audio >= 1 && n_audio <= max_audio, "run: %d windows exceed the task capacity %d", n_audio, max_audio);
     m->use();
+    const double t0 = now_ms();
     m->encoder_from_mel_t(n_audio);  // decode/mod.rs:296
     run_encoded(n_audio, out);
+    t_encoder_ms += 0;  // encoder is asynchronous; its time is attributed inside run_encoded (first sync)
+    (void)t0;
 }
 
 void DecodeTask::run_encoded(int n_audio, wrs_decode_result* out) {
@@ -261,8 +269,13 @@ void DecodeTask::run_encoded(int n_audio, wrs_decode_result* out) {
     WRS_REQUIRE(S <= m->n_ctx, "prompt of %d tokens exceeds n_text_ctxs %d (the reference panics slicing positional_embedding)", S, m->n_ctx);
     hipStream_t s = m->stream;
 
+    double tA = now_ms();
     m->load_cross_kv(st, m->enc_ws.xa16.as<half_t>(), n_audio);
     launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m->n_ctx, m->n_ctx, st.r_cap, G, s);
+    HIP_CHECK(hipStreamSynchronize(s));  // attribute encoder + cross-K/V time (everything queued so far)
+    t_encoder_ms = now_ms() - tA;
+    t_prefill_ms = t_steps_ms = t_host_ms = 0;
+    tA = now_ms();
 
     // host state (decode/mod.rs:297-325)
     rows.assign(R, initial_tokens);
@@ -300,13 +313,17 @@ void DecodeTask::run_encoded(int n_audio, wrs_decode_result* out) {
         }
     }
     if (m->timer && m->timer->enabled) { HIP_CHECK(hipStreamSynchronize(s)); m->timer->collect(); }
+    t_prefill_ms = now_ms() - tA;
 
+    tA = now_ms();
     bool completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, true) : update_greedy(n_audio, true);
     record_trace(R);
     n_steps = 1;
+    t_host_ms += now_ms() - tA;
 
     for (int i = 1; i < sample_len; ++i) {  // decode/mod.rs:234-277
         if (completed || (int)rows[0].size() > m->n_ctx) break;
+        tA = now_ms();
         StepParams* sp = st.sp_h();
         sp->cache_pos = S + i - 1;
         sp->pos_idx = position_quirk ? i : S + i - 1;
@@ -317,11 +334,16 @@ void DecodeTask::run_encoded(int n_audio, wrs_decode_result* out) {
             st.src_h()[r] = sources[r];
             st.tsmode_h()[r] = timestamps ? ts_mode_of(rows[r], S, ids.ts_begin) : 0;
         }
+        const double t1 = now_ms();
         step_decode(R);
+        const double t2 = now_ms();
         if (m->timer && m->timer->enabled) m->timer->collect();
         completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, false) : update_greedy(n_audio, false);
         record_trace(R);
         n_steps = i + 1;
+        t_steps_ms += t2 - t1;
+        t_host_ms += (t1 - tA) + (now_ms() - t2);
+        tA = now_ms();
     }
     finalize(n_audio, out);
     out->n_steps = n_steps;

@@ -41,6 +41,8 @@ struct DecodeTask {
     std::vector<std::vector<FinishedSeq>> finished;  // per audio, admission order
     std::vector<double> no_speech;
     int n_steps = 0;
+    // wall-clock split of the last run (ms): encoder+cross-KV (incl. wait), prefill, device decode steps, host sequencer
+    double t_encoder_ms = 0, t_prefill_ms = 0, t_steps_ms = 0, t_host_ms = 0;
 
     // trace (test aid)
     std::vector<int32_t> tr_tokens, tr_src;

@@ -118,7 +118,7 @@ void launch_mel_prep(const float* mel, int64_t n_batch, int64_t n_frames, int64_
 // One wave per row; the row lives in registers (D <= 64*4*NV), two-pass mean / variance in fp32.
 template <int NV>  // float4 vectors per lane
 __device__ __forceinline__ void ln_row(floatx4 (&v)[NV], int D, int lane, const float* __restrict__ g,
-                                       const float* __restrict__ b, half_t* o16, float* o32) {
+                                       const float* __restrict__ b, half_t* o16, float* o32, int packed_row = -1) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -148,7 +148,10 @@ __device__ __forceinline__ void ln_row(floatx4 (&v)[NV], int D, int lane, const 
             floatx4 y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = (v[i][r] - mean) * rstd * gg[r] + bb[r];
-            if (o16) *reinterpret_cast<half4*>(o16 + c) = half4{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+            if (o16) {
+                half_t* dst = packed_row >= 0 ? o16 + pa_off(packed_row, c, D >> 5) : o16 + c;
+                *reinterpret_cast<half4*>(dst) = half4{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+            }
             if (o32) *reinterpret_cast<floatx4*>(o32 + c) = y;
         }
     }
@@ -248,16 +251,44 @@ __global__ __launch_bounds__(256) void finish_residual_ln_kernel(float* __restri
             half4 y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = (_Float16)((v[i][r] - mean) * rstd * gg[r] + bb[r]);
-            *reinterpret_cast<half4*>(xn + (int64_t)row * D + c) = y;
+            *reinterpret_cast<half4*>(xn + pa_off(row, c, D >> 5)) = y;  // packed activation order
         }
     }
 }
 
 void launch_finish_residual_ln(float* x, const float* slab, int ksplit, int m_pad, const float* bias, const float* g,
                                const float* b, int M, int D, half_t* xn, hipStream_t s) {
-    WRS_REQUIRE(D % 4 == 0 && D <= 2048, "finish_residual_ln: D=%d unsupported", D);
+    WRS_REQUIRE(D % 32 == 0 && D <= 2048, "finish_residual_ln: D=%d unsupported", D);
     if (D <= 1024) finish_residual_ln_kernel<1><<<M, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
     else finish_residual_ln_kernel<2><<<M, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
+}
+
+// MLP-1 finish: split-K reduction + bias + exact GELU (reference model.rs:279-286) -> packed fp16 activations
+__global__ __launch_bounds__(256) void finish_act_kernel(const float* __restrict__ slab, int ksplit, int m_pad,
+                                                         const float* __restrict__ bias, int act, int M, int N,
+                                                         half_t* __restrict__ out) {
+    const int nq = N >> 2;
+    const int64_t total = (int64_t)M * nq;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / nq), n = (int)(i % nq) * 4;
+        floatx4 a = *reinterpret_cast<const floatx4*>(slab + (int64_t)m * N + n);
+        for (int sidx = 1; sidx < ksplit; ++sidx) a += *reinterpret_cast<const floatx4*>(slab + ((int64_t)sidx * m_pad + m) * N + n);
+        a += *reinterpret_cast<const floatx4*>(bias + n);
+        half4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = a[r];
+            if (act) x = 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+            y[r] = (_Float16)x;
+        }
+        *reinterpret_cast<half4*>(out + pa_off(m, n, N >> 5)) = y;
+    }
+}
+void launch_finish_act(const float* slab, int ksplit, int m_pad, const float* bias, int act, int M, int N, half_t* out,
+                       hipStream_t s) {
+    WRS_REQUIRE(N % 32 == 0 && M >= 1 && ksplit >= 1, "finish_act: bad shape");
+    const int64_t total = (int64_t)M * (N / 4);
+    finish_act_kernel<<<(unsigned)std::min<int64_t>(cdiv(total, 256), 4096), 256, 0, s>>>(slab, ksplit, m_pad, bias, act, M, N, out);
 }
 
 // reference model.rs:503-506: token_emb(tokens) + position_emb[offset..]; fused with the first block's attn_ln.
@@ -285,7 +316,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const half_t* __restrict_
             v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    ln_row<NV>(v, D, lane, g, b, xn + (int64_t)row * D, nullptr);
+    ln_row<NV>(v, D, lane, g, b, xn, nullptr, row);  // packed activation order
 }
 
 void launch_embed_ln(const half_t* emb, const float* pos, const StepParams* sp, const int* tokens, const float* g,

@@ -248,6 +248,7 @@ struct SkinnyParams {
     int act;
     void* c;
     int64_t ldc;
+    int c_packed;
     half_t* kcache;
     half_t* vcache;
     int d_model;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
 
     const half_t* w0 = p.wp + ((int64_t)(blockIdx.x * 2 + 0) * p.ksteps) * 512 + lane * 8;
     const half_t* w1 = p.wp + ((int64_t)(blockIdx.x * 2 + 1) * p.ksteps) * 512 + lane * 8;
-    const half_t* ab = p.a + (int64_t)(lane & 15) * p.K + (lane >> 4) * 8;
+    const half_t* ab = p.a + lane * 8;  // packed activations: fragment (mt, ks) at ((mt * ksteps + ks) * 512) halfs
 
     half8 wf0[SK_NKS], wf1[SK_NKS];
 #pragma unroll
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
     if (ks_begin + wave < ks_end) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-            af[0][mt] = *reinterpret_cast<const half8*>(ab + (int64_t)mt * 16 * p.K + (ks_begin + wave) * 32);
+            af[0][mt] = *reinterpret_cast<const half8*>(ab + ((int64_t)mt * p.ksteps + (ks_begin + wave)) * 512);
     }
 #pragma unroll
     for (int i = 0; i < SK_NKS; ++i) {
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
             if (i + 1 < SK_NKS && ks + 4 < ks_end) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    af[(i + 1) & 1][mt] = *reinterpret_cast<const half8*>(ab + (int64_t)mt * 16 * p.K + (ks + 4) * 32);
+                    af[(i + 1) & 1][mt] = *reinterpret_cast<const half8*>(ab + ((int64_t)mt * p.ksteps + (ks + 4)) * 512);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
                         if (n + r < p.N) dst[r] = v[r];
                 }
             } else if (p.kind == SK_F16) {
-                half_t* dst = reinterpret_cast<half_t*>(p.c) + (int64_t)m * p.ldc + n;
+                half_t* dst = reinterpret_cast<half_t*>(p.c) + (p.c_packed ? pa_off(m, n, p.N >> 5) : (int64_t)m * p.ldc + n);
                 *reinterpret_cast<half4*>(dst) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             } else {  // SK_QKV_SELF
                 const int region = n / p.d_model, nl = n - region * p.d_model;
@@ -387,12 +388,13 @@ void launch_gemm_skinny(const half_t* a, const half_t* w_packed, int M, int64_t 
     WRS_REQUIRE(cdiv(K / 32 / ksplit, 4) <= SK_NKS, "gemm_skinny: K=%ld with ksplit %d exceeds %d k-steps per wave", (long)K, ksplit, SK_NKS);
     if (e.kind == SK_F16 || e.kind == SK_QKV_SELF || e.kind == SK_SLAB)
         WRS_REQUIRE(N % 4 == 0 && (e.kind == SK_SLAB || e.ldc % 4 == 0), "gemm_skinny: N and ldc must be multiples of 4");
+    if (e.c_packed) WRS_REQUIRE(e.kind == SK_F16 && N % 32 == 0, "gemm_skinny: packed output needs SK_F16 and N %% 32 == 0");
     if (e.kind == SK_QKV_SELF)
         WRS_REQUIRE(e.sp && e.kcache && e.vcache && e.d_model > 0 && N == 3 * e.d_model && e.d_model % 4 == 0, "gemm_skinny: bad QKV epilogue");
     SkinnyParams p;
     p.a = a; p.wp = w_packed; p.M = M; p.N = (int)N; p.K = (int)K; p.ksteps = (int)(K / 32); p.ksplit = ksplit;
     p.m_pad = m_pad; p.kind = e.kind; p.bias = e.bias; p.scale = e.scale; p.scale_n_end = e.scale_n_end;
-    p.act = e.act; p.c = e.c; p.ldc = e.ldc; p.kcache = e.kcache; p.vcache = e.vcache; p.d_model = (int)e.d_model;
+    p.act = e.act; p.c = e.c; p.ldc = e.ldc; p.c_packed = e.c_packed; p.kcache = e.kcache; p.vcache = e.vcache; p.d_model = (int)e.d_model;
     p.cache_row_stride = e.cache_row_stride; p.phys_mul = e.phys_mul; p.sp = e.sp;
     dim3 grid((unsigned)(n_pad / 32), (unsigned)ksplit);
     switch (m_pad / 16) {
@@ -400,6 +402,146 @@ void launch_gemm_skinny(const half_t* a, const half_t* w_packed, int M, int64_t 
         WRS_SK(1) WRS_SK(2) WRS_SK(4) WRS_SK(6) WRS_SK(8) WRS_SK(10) WRS_SK(12) WRS_SK(16) WRS_SK(20)
 #undef WRS_SK
         default: WRS_THROW(WRS_EINVAL, "gemm_skinny: unsupported m_pad %d", m_pad);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ decode GEMM
+// Latency-optimised split-K GEMM for the decode step (M <= 320 rows, weights streamed once from HBM).
+// The step's GEMMs are tiny (3-13 MB of weights, ~0.5 GFLOP): a kernel costs launch + memory round trips, so
+// the structure is "request everything, wait once, compute":
+//   workgroup = 64 output columns (one 16-column tile per wave) x KSW k-steps x MT row tiles
+//   * activation panel [MT x kps] fragments (<= 100 KiB) goes global -> LDS with direct-to-LDS loads
+//     (global_load_lds_dwordx4: no VGPRs, 1 KiB contiguous per wave instruction thanks to the packed
+//     activation layout), shared by the 4 waves;
+//   * each wave requests its kps weight fragments straight into registers (lane-linear 1 KiB reads);
+//   * one barrier, then kps x MT MFMAs per wave with activation fragments read lane-linearly from LDS
+//     (conflict-free ds_read_b128);
+//   * partial sums go to slab[blockIdx.y] with one 16-byte store per lane per row tile; the consumer kernel
+//     reduces the slabs in fixed order (deterministic, unlike float atomics).
+template <int MT, int KPS>
+__global__ __launch_bounds__(256) void gemm_dec_kernel(const half_t* __restrict__ a, const half_t* __restrict__ wp,
+                                                       float* __restrict__ slab, int M, int N, int ksteps, int m_pad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dec_smem[];
+    // [4 waves * KPS weight fragments][MT * KPS activation fragments], 64 lanes x 16 B each
+    half8* wlds = reinterpret_cast<half8*>(dec_smem);
+    half8* alds = wlds + (size_t)4 * KPS * 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ntile = blockIdx.x * 4 + wave;
+    const int ks0 = blockIdx.y * KPS;
+    const int mt0 = blockIdx.z * MT;  // activation buffers always hold a multiple of MT row tiles (skinny_m_pad)
+
+#if !(defined(DEC_ABLATE) && DEC_ABLATE == 2)
+    // request everything: this wave's weight fragments, then its share of the activation panel.
+    // Direct-to-LDS loads are asynchronous, use no VGPRs and cannot be sunk below the barrier by the compiler.
+    const half_t* wbase = wp + ((int64_t)ntile * ksteps + ks0) * 512 + lane * 8;
+#pragma unroll
+    for (int i = 0; i < KPS; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + (int64_t)i * 512),
+                                         (__attribute__((address_space(3))) void*)(wlds + (size_t)(wave * KPS + i) * 64), 16, 0, 0);
+    // row tile mt is fetched by wave (mt & 3): KPS contiguous KiB per row tile in the packed activation layout
+    for (int mt = wave; mt < MT; mt += 4) {
+        const half_t* src = a + ((int64_t)(mt0 + mt) * ksteps + ks0) * 512 + lane * 8;
+#pragma unroll
+        for (int kk = 0; kk < KPS; ++kk)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)kk * 512),
+                                             (__attribute__((address_space(3))) void*)(alds + (size_t)(mt * KPS + kk) * 64), 16, 0, 0);
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave's direct-to-LDS loads have landed and are visible
+#if defined(DEC_ABLATE) && DEC_ABLATE == 1
+    return;
+#endif
+
+    floatx4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // no per-tile guards: every LDS read of a k-step is issued before its MFMAs (rows >= M are only masked at the store)
+#pragma unroll
+    for (int i = 0; i < KPS; ++i) {
+        const half8 wf = wlds[(size_t)(wave * KPS + i) * 64 + lane];
+        half8 af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = alds[(size_t)(mt * KPS + i) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af[mt], acc[mt], 0, 0, 0);
+    }
+    const int n = ntile * 16 + 4 * (lane >> 4);
+    if (n < N) {
+        float* dst = slab + ((int64_t)blockIdx.y * m_pad + mt0 * 16 + (lane & 15)) * N + n;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            if ((mt0 + mt) * 16 + (lane & 15) < M) *reinterpret_cast<floatx4*>(dst + (int64_t)mt * 16 * N) = acc[mt];
+    }
+}
+
+// k-steps per workgroup: the largest supported divisor of `ksteps` (the kernel is instantiated for these)
+static int pick_kps(int ksteps, int cap) {
+    static const int opts[] = {16, 10, 8, 6, 5, 4, 3, 2, 1};
+    for (int d : opts)
+        if (d <= cap && ksteps % d == 0) return d;
+    return 1;
+}
+
+// row tiles per workgroup: m_pad/16 is 1, 2, 4, 6, 8, 10, 12, 16 or 20 (skinny_m_pad)
+static int pick_mt(int mtiles, int cap) {
+    static const int opts[] = {10, 8, 6, 5, 4, 3, 2, 1};
+    for (int d : opts)
+        if (d <= cap && mtiles % d == 0) return d;
+    return 1;
+}
+
+int gemm_dec_plan(int M, int64_t N, int64_t K, int* kps_out, int* mt_block_out) {
+    const int ksteps = (int)(K / 32);
+    const int mtiles = skinny_m_pad(M) / 16;
+    const bool deep = ksteps >= 80;  // K >= 2560 (MLP-2): 16 k-steps x <= 5 row tiles per workgroup, rows split over grid.z
+    const int kps = pick_kps(ksteps, deep ? 16 : 10);
+    const int mt = pick_mt(mtiles, kps > 10 ? 5 : 10);  // LDS: (mt + 4) * kps KiB <= 160 KiB
+    if (kps_out) *kps_out = kps;
+    if (mt_block_out) *mt_block_out = mt;
+    return ksteps / kps;  // ksplit = number of slabs
+}
+
+template <int MT, int KPS>
+static void launch_dec(const half_t* a, const half_t* wp, float* slab, int M, int N, int n_pad, int ksteps, int mtiles, int m_pad,
+                       hipStream_t s) {
+    const size_t shmem = (size_t)(MT + 4) * KPS * 1024;  // weight fragments of 4 waves + activation panel
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dec_kernel<MT, KPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(n_pad / 64), (unsigned)(ksteps / KPS), (unsigned)(mtiles / MT));
+    gemm_dec_kernel<MT, KPS><<<grid, 256, shmem, s>>>(a, wp, slab, M, N, ksteps, m_pad);
+}
+
+template <int MT>
+static void launch_dec_k(int kps, const half_t* a, const half_t* wp, float* slab, int M, int N, int n_pad, int ksteps, int mtiles,
+                         int m_pad, hipStream_t s) {
+    switch (kps) {
+#define WRS_DK(K_) case K_: launch_dec<MT, K_>(a, wp, slab, M, N, n_pad, ksteps, mtiles, m_pad, s); break;
+        WRS_DK(1) WRS_DK(2) WRS_DK(3) WRS_DK(4) WRS_DK(5) WRS_DK(6) WRS_DK(8) WRS_DK(10)
+#undef WRS_DK
+        case 16:
+            if constexpr (MT <= 5) launch_dec<MT, 16>(a, wp, slab, M, N, n_pad, ksteps, mtiles, m_pad, s);
+            else WRS_THROW(WRS_EINVAL, "gemm_dec: kps 16 needs <= 5 row tiles per workgroup");
+            break;
+        default: WRS_THROW(WRS_EINVAL, "gemm_dec: unsupported k-steps per workgroup %d", kps);
+    }
+}
+
+void launch_gemm_dec(const half_t* a, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K, float* slab, hipStream_t s) {
+    const int m_pad = skinny_m_pad(M);
+    WRS_REQUIRE(m_pad > 0, "gemm_dec: M=%d exceeds 320 rows", M);
+    WRS_REQUIRE(K % 32 == 0 && n_pad % 64 == 0 && N <= n_pad && N % 4 == 0, "gemm_dec: bad shape N=%ld n_pad=%ld K=%ld", (long)N, (long)n_pad, (long)K);
+    int kps = 0, mt = 0;
+    gemm_dec_plan(M, N, K, &kps, &mt);
+    const int ksteps = (int)(K / 32), mtiles = m_pad / 16;
+    switch (mt) {
+#define WRS_DM(M_) case M_: launch_dec_k<M_>(kps, a, w_packed, slab, M, (int)N, (int)n_pad, ksteps, mtiles, m_pad, s); break;
+        WRS_DM(1) WRS_DM(2) WRS_DM(3) WRS_DM(4) WRS_DM(5) WRS_DM(6) WRS_DM(8) WRS_DM(10)
+#undef WRS_DM
+        default: WRS_THROW(WRS_EINVAL, "gemm_dec: unsupported row tiles per workgroup %d", mt);
     }
 }
 
@@ -456,20 +598,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int64_t mm = m0 + wx * 32 + j * 16 + (lane & 15);
-        if (mm >= M) continue;
+        const int64_t mm_raw = m0 + wx * 32 + j * 16 + (lane & 15);
+        const bool valid = mm_raw < M;            // no early exit: the wave-level reduction below needs every lane
+        const int64_t mm = valid ? mm_raw : M - 1;
         float row_max = -3.0e38f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int n = n0 + wy * 32 + i * 16 + 4 * (lane >> 4);
             if (MODE == 0) {
                 const int b0 = n >> 1;
-                if (b0 < ldc) c[mm * ldc + b0] = acc[i][j][0] * acc[i][j][0] + acc[i][j][1] * acc[i][j][1];
-                if (b0 + 1 < ldc) c[mm * ldc + b0 + 1] = acc[i][j][2] * acc[i][j][2] + acc[i][j][3] * acc[i][j][3];
+                if (valid && b0 < ldc) c[mm * ldc + b0] = acc[i][j][0] * acc[i][j][0] + acc[i][j][1] * acc[i][j][1];
+                if (valid && b0 + 1 < ldc) c[mm * ldc + b0 + 1] = acc[i][j][2] * acc[i][j][2] + acc[i][j][3] * acc[i][j][3];
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (n + r < N) {
+                    if (valid && n + r < N) {
                         const float x = log10f(fmaxf(acc[i][j][r], 1e-10f));
                         c[mm * ldc + n + r] = x;
                         row_max = fmaxf(row_max, x);
@@ -477,7 +620,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 }
             }
         }
-        if (MODE == 1 && row_max > -3.0e38f) atomicMax(maxbuf + mm / rpb, float_order_key(row_max));
+        if (MODE == 1) {
+            // one atomic per wave when the whole wave belongs to one recording (the common case); a
+            // per-lane atomicMax on one address serialises the chip (measured 9.5 ms for 32 windows)
+            const int64_t bidx = mm / rpb;
+            const int64_t b0 = __shfl(bidx, 0);
+            if (__all(bidx == b0)) {
+                float wm = row_max;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+                if (lane == 0 && wm > -3.0e38f) atomicMax(maxbuf + b0, float_order_key(wm));
+            } else if (row_max > -3.0e38f) {
+                atomicMax(maxbuf + bidx, float_order_key(row_max));
+            }
+        }
     }
 }
 

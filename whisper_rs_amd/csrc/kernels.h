@@ -18,6 +18,14 @@ struct StepParams {
 };
 // followed in the same allocation by: int tokens[cap]; int src[cap]; int ts_mode[cap];
 
+// ---------------------------------------------------------------- packed activations (decode step)
+// Decode-step activations X [M, K] fp16 are kept in MFMA B-operand fragment order
+//   [M_pad/16][K/32][64 lanes][8 halfs],  element (m, k) -> lane = ((k & 31) >> 3) * 16 + (m & 15), j = k & 7
+// so that a wave fetches a 16x32 fragment as ONE contiguous 1 KiB read (lane-linear 16 B per lane).
+static inline __host__ __device__ int64_t pa_off(int m, int k, int ksteps) {
+    return ((int64_t)((m >> 4) * ksteps + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (m & 15)) * 8 + (k & 7);
+}
+
 // ---------------------------------------------------------------- weights packing
 // packed MFMA-fragment layout of a [N, K] row-major matrix: [Npad/16][K/32][64 lanes][8 halfs],
 // element (nt, ks, l, j) = W[nt*16 + (l & 15)][ks*32 + 8*(l >> 4) + j]; rows >= N are zero.
@@ -65,6 +73,7 @@ struct SkinnyEpi {
     int act = 0;
     void* c = nullptr;   // SK_F16: half [M, N]; SK_F32: float [M, N]; SK_SLAB: float [ksplit][m_pad][N]; SK_QKV_SELF: q half [M, D]
     int64_t ldc = 0;
+    int c_packed = 0;    // SK_F16 only: write C in packed-activation order (K' = N) instead of row-major
     // SK_QKV_SELF: N = 3*D; n in [D,2D) -> kcache, [2D,3D) -> vcache at [phys_row][cache_pos][n]
     half_t* kcache = nullptr;
     half_t* vcache = nullptr;
@@ -73,10 +82,14 @@ struct SkinnyEpi {
     int phys_mul = 1;
     const StepParams* sp = nullptr;
 };
-// C[M, N] = A[M, K] (row-major fp16, lda = K) * W^T ; W packed (n_pad multiple of 32, K multiple of 128)
+// C[M, N] = A[M, K] (PACKED activation order, see pa_off) * W^T ; W packed (n_pad multiple of 32)
 void launch_gemm_skinny(const half_t* a, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K,
                         int ksplit, const SkinnyEpi& epi, hipStream_t s);
 int skinny_m_pad(int M);
+// latency-optimised decode GEMM: slab[ks][m_pad][N] (fp32 partial sums) = A (packed activations) * W^T split over
+// ksplit = gemm_dec_plan(...) k-slices; the consumer kernel reduces the slabs in order.
+int gemm_dec_plan(int M, int64_t N, int64_t K, int* kps_out, int* mt_block_out);
+void launch_gemm_dec(const half_t* a, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K, float* slab, hipStream_t s);
 
 // ---------------------------------------------------------------- f32 GEMM (STFT, mel filterbank)
 // mode 0: power spectrum. C[m][n/2] = acc[2b]^2 + acc[2b+1]^2 (interleaved re/im columns), ldc floats
@@ -100,10 +113,13 @@ void launch_mel_prep(const float* mel, int64_t n_batch, int64_t n_frames, int64_
 // y = LN(x) * g + b (eps 1e-5); x fp32 [M, D]; out16 and/or out32 may be null
 void launch_layernorm(const float* x, const float* g, const float* b, int64_t M, int D, half_t* out16, float* out32,
                       hipStream_t s);
-// x[m] += bias + sum_s slab[s][m]; xn = LN(x).  slab [ksplit][m_pad][D]
+// x[m] += bias + sum_s slab[s][m]; xn = LN(x) in PACKED activation order.  slab [ksplit][m_pad][D]
 void launch_finish_residual_ln(float* x, const float* slab, int ksplit, int m_pad, const float* bias, const float* g,
                                const float* b, int M, int D, half_t* xn, hipStream_t s);
-// x[r] = emb[token[r]] + pos[pos_idx]; xn = LN(x)
+// x[r] = emb[token[r]] + pos[pos_idx]; xn = LN(x) in PACKED activation order
+// out (PACKED activation order, K' = N) = act(sum_s slab[s][m][:] + bias); slab [ksplit][m_pad][N]; act 1 = exact GELU
+void launch_finish_act(const float* slab, int ksplit, int m_pad, const float* bias, int act, int M, int N, half_t* out,
+                       hipStream_t s);
 void launch_embed_ln(const half_t* emb, const float* pos, const StepParams* sp, const int* tokens, const float* g,
                      const float* b, int M, int D, float* x, half_t* xn, hipStream_t s);
 
@@ -116,13 +132,16 @@ void launch_pack_kv(const half_t* src, int64_t ld, int64_t k_off, int64_t v_off,
 // encoder-style: every 16-query tile of [n_batch, Tq] attends to all T keys. q [n_batch*Tq, ldq] at col h*64
 void launch_attn_full(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_batch, int Tq, int T,
                       int H, half_t* out, int64_t ldo, hipStream_t s);
-// decode cross-attention: the G (<=16) rows of one audio share that audio's packed K/V
-void launch_attn_cross(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_audio, int G, int T,
-                       int H, half_t* out, int64_t ldo, hipStream_t s);
-// decode self-attention over the ancestry-indirected K/V cache; one wave per (row, head)
-void launch_attn_self(const half_t* q, int64_t ldq, const half_t* kc, const half_t* vc, const int* anc_base,
-                      int64_t anc_buf_stride, int n_ctx, int n_rows, int phys_mul, int H, int D, const StepParams* sp,
-                      half_t* out, int64_t ldo, hipStream_t s);
+// decode cross-attention: the G (<=16) rows of one audio share that audio's packed K/V; out in PACKED activation
+// order.  Q = (sum_s q_slab[s] + q_bias) * q_scale: the split-K slabs [ksplit][m_pad][H*64] of the query projection.
+void launch_attn_cross(const float* q_slab, int q_ksplit, int q_m_pad, const float* q_bias, float q_scale, const half_t* kp,
+                       const half_t* vp, int n_audio, int G, int T, int H, half_t* out, hipStream_t s);
+// decode self-attention over the ancestry-indirected K/V cache; one wave per (row, head); out in PACKED activation
+// order.  q/k/v of the new token come from the QKV projection's split-K slabs [ksplit][m_pad][3D]; k/v are appended
+// to kc/vc [phys_row][n_ctx][D] at sp->cache_pos.
+void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc,
+                      const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, int phys_mul, int H, int D,
+                      const StepParams* sp, half_t* out, hipStream_t s);
 void launch_anc_init(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_phys_rows, int G, hipStream_t s);
 void launch_anc_update(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, const StepParams* sp,
                        const int* src, hipStream_t s);

@@ -419,10 +419,9 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.anc.alloc((size_t)2 * r_cap * n_ctx * 4);
     st.x.alloc((size_t)m_pad * D * 4);
     st.xn.alloc((size_t)m_pad * D * 2);
-    st.q.alloc((size_t)m_pad * D * 2);
     st.att.alloc((size_t)m_pad * D * 2);
     st.h.alloc((size_t)m_pad * 4 * D * 2);
-    st.slab.alloc((size_t)st.slab_ksplit_cap * m_pad * D * 4);
+    st.slab.alloc((size_t)40 * m_pad * 4 * D * 4);  // ksplit (<= K/32 <= 40 for N = 4D; <= 160 for N = D) * m_pad * N floats
     st.logits.alloc((size_t)r_cap * V * 4);
     st.ckv_tmp.alloc((size_t)a_cap * T * 2 * D * 2);
     st.sp_dev.alloc(st.sp_bytes());
@@ -457,18 +456,20 @@ void Model::load_cross_kv(DecState& st, const half_t* xa16, int n_audio) {
     st.n_audio = n_audio;
 }
 
-// split-K factor of a slab GEMM: enough workgroups (N/32 * ksplit) to spread the weight stream over the
-// chip, and at most 10 k-steps per wave so every weight fragment is requested up front (gemm.hip SK_NKS)
+// split-K factor of a decode GEMM: enough workgroups (N/32 * ksplit >= ~200) to spread the weight stream over
+// the 256 CUs, at most 10 k-steps per wave (gemm.hip SK_NKS) and at least 4 k-steps per workgroup.  The total
+// activation traffic of a GEMM does not depend on ksplit (every workgroup reads only its k-slice of A), so
+// splitting only costs slab bytes (ksplit * M * N * 4), which the consumer kernel reduces.
 static int pick_ksplit(int64_t N, int64_t K, int cap) {
     const int ksteps = (int)(K / 32);
     const int wgs = (int)(N / 32);
     int ks = 1;
-    while (ks * 2 <= cap && ksteps % (ks * 2) == 0 && (ksteps / ks > 40 || (wgs * ks < 160 && ksteps / (ks * 2) >= 8))) ks *= 2;
+    while (ks * 2 <= cap && ksteps % (ks * 2) == 0 && ksteps / (ks * 2) >= 4 && (wgs * ks < 200 || ksteps / ks > 40)) ks *= 2;
     return ks;
 }
 
 void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits) {
-    WRS_REQUIRE(rows >= 1 && rows * phys_mul <= st.r_cap * std::max(1, phys_mul) && rows <= st.r_cap, "decoder_step: bad row count %d", rows);
+    WRS_REQUIRE(rows >= 1 && rows <= st.r_cap, "decoder_step: bad row count %d", rows);
     WRS_REQUIRE((rows - 1) * phys_mul < st.r_cap, "decoder_step: physical row out of range");
     WRS_REQUIRE(rows % q_per_audio == 0 && rows / q_per_audio <= st.n_audio, "decoder_step: rows %d do not match %d audios x %d", rows, st.n_audio, q_per_audio);
     const float scale = std::pow((float)(D / H), -0.25f);
@@ -478,7 +479,15 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     const size_t cross_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
     const int n_audio = rows / q_per_audio;
     const double wD = (double)D * D * 2;  // bytes of a [D, D] fp16 matrix
-    const int ks_d = pick_ksplit(D, D, st.slab_ksplit_cap), ks_4d = pick_ksplit(D, 4 * (int64_t)D, st.slab_ksplit_cap);
+    const int ks_qkv = gemm_dec_plan(rows, 3 * D, D, nullptr, nullptr), ks_d = gemm_dec_plan(rows, D, D, nullptr, nullptr),
+              ks_m1 = gemm_dec_plan(rows, 4 * D, D, nullptr, nullptr), ks_m2 = gemm_dec_plan(rows, D, 4 * (int64_t)D, nullptr, nullptr);
+    const int mp = st.m_pad_for(rows);
+    float* slab = st.slab.as<float>();
+    auto gemm_slab = [&](const char* name, const half_t* a, const half_t* w, int64_t N, int64_t K, int ks, double bytes) {
+        Timed tm(timer, name, stream, bytes);
+        (void)ks;
+        launch_gemm_dec(a, w, rows, N, round_up(N, 128), K, slab, stream);
+    };
 
     if (update_anc) {
         Timed tm(timer, "dec_anc_update", stream);
@@ -491,36 +500,21 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     }
     for (int l = 0; l < L_dec; ++l) {
         const BlockW& b = dec[l];
-        {
-            Timed tm(timer, "dec_gemm_qkv", stream, 3 * wD);
-            SkinnyEpi e;
-            e.kind = SK_QKV_SELF; e.bias = b.qkv_b; e.scale = scale; e.scale_n_end = 2 * D; e.c = st.q.p; e.ldc = D;
-            e.kcache = st.kc.as<half_t>() + l * kv_layer; e.vcache = st.vc.as<half_t>() + l * kv_layer;
-            e.d_model = D; e.cache_row_stride = (int64_t)n_ctx * D; e.phys_mul = phys_mul; e.sp = sp;
-            launch_gemm_skinny(st.xn.as<half_t>(), b.qkv_w, rows, 3 * D, round_up(3 * D, 128), D, 1, e, stream);
-        }
+        // x + attn(attn_ln(x))   (model.rs:302-305)
+        gemm_slab("dec_gemm_qkv", st.xn.as<half_t>(), b.qkv_w, 3 * D, D, ks_qkv, 3 * wD);
         {
             Timed tm(timer, "dec_attn_self", stream);
-            launch_attn_self(st.q.as<half_t>(), D, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer,
-                             st.anc.as<int>(), anc_stride, n_ctx, rows, phys_mul, H, D, sp, st.att.as<half_t>(), D, stream);
+            launch_attn_self(slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer,
+                             st.anc.as<int>(), anc_stride, n_ctx, rows, phys_mul, H, D, sp, st.att.as<half_t>(), stream);
         }
-        {
-            Timed tm(timer, "dec_gemm_out", stream, wD);
-            SkinnyEpi e;
-            e.kind = SK_SLAB; e.c = st.slab.p;
-            launch_gemm_skinny(st.att.as<half_t>(), b.out_w, rows, D, round_up(D, 128), D, ks_d, e, stream);
-        }
+        gemm_slab("dec_gemm_out", st.att.as<half_t>(), b.out_w, D, D, ks_d, wD);
         {
             Timed tm(timer, "dec_finish_ln", stream);
-            launch_finish_residual_ln(st.x.as<float>(), st.slab.as<float>(), ks_d, st.m_pad_for(rows), b.out_b, b.cross_ln_g,
-                                      b.cross_ln_b, rows, D, st.xn.as<half_t>(), stream);
+            launch_finish_residual_ln(st.x.as<float>(), slab, ks_d, mp, b.out_b, b.cross_ln_g, b.cross_ln_b, rows, D,
+                                      st.xn.as<half_t>(), stream);
         }
-        {
-            Timed tm(timer, "dec_gemm_cq", stream, wD);
-            SkinnyEpi e;
-            e.kind = SK_F16; e.bias = b.cq_b; e.scale = scale; e.scale_n_end = D; e.c = st.q.p; e.ldc = D;
-            launch_gemm_skinny(st.xn.as<half_t>(), b.cq_w, rows, D, round_up(D, 128), D, 1, e, stream);
-        }
+        // + cross_attn(cross_attn_ln(x), xa)   (model.rs:309-310)
+        gemm_slab("dec_gemm_cq", st.xn.as<half_t>(), b.cq_w, D, D, ks_d, wD);
         {
             Timed tm(timer, "dec_attn_cross", stream, (double)n_audio * 2.0 * T * D * 2.0);
             const bool sample = cross_ev_now && (l % cross_ev_stride == 0);
@@ -529,39 +523,28 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
                 while ((int)cross_ev.size() < 2 * (slot + 1)) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); cross_ev.push_back(e); }
                 HIP_CHECK(hipEventRecord(cross_ev[2 * slot], stream));
             }
-            launch_attn_cross(st.q.as<half_t>(), D, st.cross_kp.as<half_t>() + l * cross_layer,
-                              st.cross_vp.as<half_t>() + l * cross_layer, n_audio, q_per_audio, T, H, st.att.as<half_t>(), D, stream);
+            launch_attn_cross(slab, ks_d, mp, b.cq_b, scale, st.cross_kp.as<half_t>() + l * cross_layer,
+                              st.cross_vp.as<half_t>() + l * cross_layer, n_audio, q_per_audio, T, H, st.att.as<half_t>(), stream);
             if (sample) HIP_CHECK(hipEventRecord(cross_ev[2 * slot + 1], stream));
         }
-        {
-            Timed tm(timer, "dec_gemm_out", stream, wD);
-            SkinnyEpi e;
-            e.kind = SK_SLAB; e.c = st.slab.p;
-            launch_gemm_skinny(st.att.as<half_t>(), b.cout_w, rows, D, round_up(D, 128), D, ks_d, e, stream);
-        }
+        gemm_slab("dec_gemm_out", st.att.as<half_t>(), b.cout_w, D, D, ks_d, wD);
         {
             Timed tm(timer, "dec_finish_ln", stream);
-            launch_finish_residual_ln(st.x.as<float>(), st.slab.as<float>(), ks_d, st.m_pad_for(rows), b.cout_b, b.mlp_ln_g,
-                                      b.mlp_ln_b, rows, D, st.xn.as<half_t>(), stream);
+            launch_finish_residual_ln(st.x.as<float>(), slab, ks_d, mp, b.cout_b, b.mlp_ln_g, b.mlp_ln_b, rows, D,
+                                      st.xn.as<half_t>(), stream);
         }
+        // + mlp(mlp_ln(x))   (model.rs:315)
+        gemm_slab("dec_gemm_mlp1", st.xn.as<half_t>(), b.mlp0_w, 4 * D, D, ks_m1, 4 * wD);
         {
-            Timed tm(timer, "dec_gemm_mlp1", stream, 4 * wD);
-            SkinnyEpi e;
-            e.kind = SK_F16; e.bias = b.mlp0_b; e.act = 1; e.c = st.h.p; e.ldc = 4 * D;
-            launch_gemm_skinny(st.xn.as<half_t>(), b.mlp0_w, rows, 4 * D, round_up(4 * D, 128), D, 1, e, stream);
+            Timed tm(timer, "dec_finish_gelu", stream);
+            launch_finish_act(slab, ks_m1, mp, b.mlp0_b, 1, rows, 4 * D, st.h.as<half_t>(), stream);
         }
-        {
-            Timed tm(timer, "dec_gemm_mlp2", stream, 4 * wD);
-            SkinnyEpi e;
-            e.kind = SK_SLAB; e.c = st.slab.p;
-            launch_gemm_skinny(st.h.as<half_t>(), b.mlp2_w, rows, D, round_up(D, 128), 4 * (int64_t)D, ks_4d, e, stream);
-        }
+        gemm_slab("dec_gemm_mlp2", st.h.as<half_t>(), b.mlp2_w, D, 4 * (int64_t)D, ks_m2, 4 * wD);
         {
             Timed tm(timer, "dec_finish_ln", stream);
             const float* g = (l + 1 < L_dec) ? dec[l + 1].attn_ln_g : ln_g;
             const float* bb = (l + 1 < L_dec) ? dec[l + 1].attn_ln_b : ln_b;
-            launch_finish_residual_ln(st.x.as<float>(), st.slab.as<float>(), ks_4d, st.m_pad_for(rows), b.mlp2_b, g, bb, rows, D,
-                                      st.xn.as<half_t>(), stream);
+            launch_finish_residual_ln(st.x.as<float>(), slab, ks_m2, mp, b.mlp2_b, g, bb, rows, D, st.xn.as<half_t>(), stream);
         }
     }
     if (want_logits) {

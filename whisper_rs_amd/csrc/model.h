@@ -39,7 +39,7 @@ struct DecState {
     DevBuf cross_kp, cross_vp;  // [L][a_cap][H][Tp*64]
     DevBuf kc, vc;              // [L][r_cap][n_ctx][D]
     DevBuf anc;                 // [2][r_cap][n_ctx]
-    DevBuf x, xn, q, att, h, slab, logits, ckv_tmp;
+    DevBuf x, xn, att, h, slab, logits, ckv_tmp;
     DevBuf sp_dev;              // StepParams + tokens[r_cap] + src[r_cap] + ts_mode[r_cap]
     PinnedBuf sp_host;
     PinnedBuf topk;             // lp [r_cap*8] f32 | id [r_cap*8] i32 | no_speech [r_cap] f32
