@@ -89,6 +89,26 @@ def cpu_baseline(dims, beam, sample_len, n_decode_steps=2):
                       f"({t_step:.2f} s/step, cross-K/V recomputed per step as the reference does) extrapolated linearly; fp32 ATen CPU"}
 
 
+def window_seed(rank):
+    """every rank decodes its own, distinct synthetic windows (independent units, no data-path collective)."""
+    return 1234 + 1000 * rank
+
+
+def max_over_ranks(elapsed, world, device):
+    """timed-region length of the job = the slowest rank's (all_reduce MAX; the only collective in the bench)."""
+    if world <= 1:
+        return elapsed
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_xrt(steps, batch, world, elapsed):
+    """audio-seconds decoded by ALL ranks in the timed region / wall seconds (weak scaling: batch is per rank)."""
+    return steps * batch * 30.0 * world / elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,7 +145,7 @@ def main():
     task = W.DecodeTask(model, ids, W.DecodeOptions(sample_len=args.sample_len, max_audio=args.batch,
                                                     token_extract_mode=W.TokenExtractMode.BeamSearch(args.beam, 1.0)))
     # synthetic 30-s windows, distinct per rank, resident in HBM before the timed region
-    audio = torch.from_numpy(synth.make_audio(args.batch, seed=1234 + 1000 * rank)).to(dev)
+    audio = torch.from_numpy(synth.make_audio(args.batch, seed=window_seed(rank))).to(dev)
     torch.cuda.synchronize()
 
     def barrier():
@@ -150,10 +170,7 @@ def main():
     split = task.last_run_times()
     task.set_cross_timing(False, args.cross_stride)
     n_steps_decoded = task.n_steps
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed, world, dev)
 
     if args.stage_profile and rank == 0:
         task.set_profiling(True)
@@ -168,8 +185,7 @@ def main():
                   f"avg {1e3 * s['ms'] / max(1, s['launches']):8.1f} us  {gbs:8.1f} GB/s {tfs:8.1f} TFLOP/s", file=sys.stderr)
 
     if rank == 0:
-        audio_seconds = args.steps * args.batch * 30.0 * world
-        value = audio_seconds / elapsed
+        value = whole_job_xrt(args.steps, args.batch, world, elapsed)
         # roofline of the dominant kernel: decode cross-attention streams every audio's packed K and V once
         # per launch: algorithmic bytes = batch * 2 (K,V) * 1500 * D * 2 B (KV_cross / L)
         rl = None

@@ -320,18 +320,23 @@ __device__ __forceinline__ void slab_chunk8(const float* __restrict__ slab, int 
 }
 
 __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) {
-    __shared__ float sc[4][512];
+    // one workgroup = (up to) 4 heads of ONE row, so the row's ancestry entries are fetched once
+    __shared__ int anc_s[512];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 4 + wave;
-    if (unit >= p.n_rows * p.H) return;  // no block-level barriers below
-    const int row = unit / p.H, h = unit % p.H;
+    const int hpb = (p.H + 3) >> 2;                 // workgroups per row
+    const int row = blockIdx.x / hpb, h = (blockIdx.x % hpb) * 4 + wave;
     const int g = lane >> 3, c = lane & 7;
     const int D = p.D;
     const int cpos = p.sp->cache_pos;  // the new token's slot; cached positions are 0..cpos-1
     const int phys = row * p.phys_mul;
     const int* anc = p.anc_base + (int64_t)p.sp->parity * p.anc_buf_stride + (int64_t)phys * p.n_ctx;
+    for (int i = threadIdx.x; i < cpos; i += 256) anc_s[i] = anc[i];
     const int64_t row_stride = (int64_t)p.n_ctx * D;
     const int col = h * 64 + c * 8;
+    if (h >= p.H) {  // surplus wave of the last head group: only takes part in the barrier
+        __syncthreads();
+        return;
+    }
 
     // new token: q, k, v chunk c from the QKV slabs
     float qv[8], kn[8], vn[8];
@@ -354,90 +359,75 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
             *reinterpret_cast<half8*>(p.vc + (int64_t)phys * row_stride + (int64_t)cpos * D + col) = v16;
         }
     }
-    // score of the new position
+    __syncthreads();  // anc_s ready
+
+    // single pass, online softmax.  State per lane: running max m (wave-uniform), partial denominator l and
+    // partial output acc[8] over the positions this lane's group g has seen; groups are merged at the end.
     float s_new = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) s_new += qv[j] * kn[j];
     s_new += __shfl_xor(s_new, 1);
     s_new += __shfl_xor(s_new, 2);
     s_new += __shfl_xor(s_new, 4);
-    float mx = s_new;
+    float m_run = s_new;  // the new position seeds the running max (weight exp(0) = 1), counted once by group 0
+    float l_run = (g == 0) ? 1.f : 0.f;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (g == 0) ? vn[j] : 0.f;
 
     for (int p0 = 0; p0 < cpos; p0 += 32) {
-        half8 kv[4];
+        half8 kv[4], vv[4];
         bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int pos = p0 + u * 8 + g;
             ok[u] = pos < cpos;
             kv[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok[u]) {
-                const int pr = anc[pos];
-                kv[u] = *reinterpret_cast<const half8*>(p.kc + (int64_t)pr * row_stride + (int64_t)pos * D + col);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float t = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t += qv[j] * (float)kv[u][j];
-            t += __shfl_xor(t, 1);
-            t += __shfl_xor(t, 2);
-            t += __shfl_xor(t, 4);
-            if (ok[u]) {
-                if (c == 0) sc[wave][p0 + u * 8 + g] = t;
-                mx = fmaxf(mx, t);
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    const float e_new = __expf(s_new - mx);
-    float sum = 0.f;
-    for (int pos = lane; pos < cpos; pos += 64) {
-        const float e = __expf(sc[wave][pos] - mx);
-        sc[wave][pos] = e;
-        sum += e;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    sum += e_new;
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    const float inv = 1.f / sum;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (g == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = e_new * vn[j];
-    }
-    for (int p0 = 0; p0 < cpos; p0 += 32) {
-        half8 vv[4];
-        float w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int pos = p0 + u * 8 + g;
             vv[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            w[u] = 0.f;
-            if (pos < cpos) {
-                const int pr = anc[pos];
-                w[u] = sc[wave][pos];
-                vv[u] = *reinterpret_cast<const half8*>(p.vc + (int64_t)pr * row_stride + (int64_t)pos * D + col);
+            if (ok[u]) {
+                const int64_t off = (int64_t)anc_s[pos] * row_stride + (int64_t)pos * D + col;
+                kv[u] = *reinterpret_cast<const half8*>(p.kc + off);
+                vv[u] = *reinterpret_cast<const half8*>(p.vc + off);
             }
         }
+        float t[4];
+        float cm = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u) {
+            float x = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += w[u] * (float)vv[u][j];
+            for (int j = 0; j < 8; ++j) x += qv[j] * (float)kv[u][j];
+            x += __shfl_xor(x, 1);
+            x += __shfl_xor(x, 2);
+            x += __shfl_xor(x, 4);
+            t[u] = ok[u] ? x : -INFINITY;
+            cm = fmaxf(cm, t[u]);
+        }
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o));
+        const float m_new = fmaxf(m_run, cm);
+        const float alpha = __expf(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float w = __expf(t[u] - m_new);  // exp(-inf) = 0 for padded slots
+            l_run += w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w * (float)vv[u][j];
+        }
+        m_run = m_new;
     }
+    // merge the 8 position groups (lanes differing in bits 3..5); l_run is replicated over c, so reduce over g only
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        acc[j] += __shfl_xor(acc[j], 8);
-        acc[j] += __shfl_xor(acc[j], 16);
-        acc[j] += __shfl_xor(acc[j], 32);
+    for (int o = 8; o < 64; o <<= 1) {
+        l_run += __shfl_xor(l_run, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o);
     }
     if (g == 0) {
+        const float inv = 1.f / l_run;
         half8 r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = (_Float16)(acc[j] * inv);
@@ -450,7 +440,7 @@ void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float*
                       const StepParams* sp, half_t* out, hipStream_t s) {
     WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && qkv_slab && qkv_bias && ksplit >= 1, "attn_self: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
     SelfAttnParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out};
-    const unsigned grid = (unsigned)cdiv((int64_t)n_rows * H, 4);
+    const unsigned grid = (unsigned)(n_rows * ((H + 3) / 4));
     attn_self_kernel<<<grid, 256, 0, s>>>(p);
 }
 
