@@ -95,12 +95,27 @@ struct AttnParams {
     int q_ksplit, q_m_pad;
     const float* q_bias;
     float q_scale;
+    int n_units;  // !SPLIT: n_batch * H
 };
 
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int h, b, qblk = 0;
+    if (SPLIT) {
+        h = blockIdx.y;
+        b = blockIdx.z;
+    } else {
+        // 1-D grid, XCD-aware: all query blocks of one (batch, head) run on ONE XCD so its packed K/V (384 KiB) is
+        // fetched into one L2 once instead of by all 8 (measured FETCH_SIZE 8x the K/V bytes before).  Speed only.
+        const int wq = (p.q_rows_per_batch + 63) >> 6;     // query blocks per (batch, head)
+        const int j = (int)(blockIdx.x >> 3);
+        const int unit = (j / wq) * 8 + (int)(blockIdx.x & 7);
+        if (unit >= p.n_units) return;
+        qblk = j % wq;
+        h = unit % p.H;
+        b = unit / p.H;
+    }
     const int qcol = lane & 15, qg = lane >> 4;
 
     int q0, n_valid;
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
         q0 = 0;
         n_valid = p.q_valid;
     } else {
-        q0 = (blockIdx.x * 4 + wave) * 16;
+        q0 = (qblk * 4 + wave) * 16;
         n_valid = p.q_rows_per_batch - q0;
         if (n_valid <= 0) return;  // whole wave out of range (no barriers in the non-split kernel)
         if (n_valid > 16) n_valid = 16;
@@ -268,16 +283,16 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
 void launch_attn_full(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_batch, int Tq, int T, int H,
                       half_t* out, int64_t ldo, hipStream_t s) {
     WRS_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && T >= 1 && Tq >= 1, "attn_full: bad shape");
-    AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, Tq, 0, out, ldo, nullptr, 0, 0, nullptr, 1.f};
-    dim3 grid((unsigned)cdiv(Tq, 64), (unsigned)H, (unsigned)n_batch);
-    attn_mfma_kernel<false><<<grid, 256, 0, s>>>(p);
+    AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, Tq, 0, out, ldo, nullptr, 0, 0, nullptr, 1.f, n_batch * H};
+    const int64_t units8 = cdiv((int64_t)n_batch * H, 8);
+    attn_mfma_kernel<false><<<(unsigned)(8 * units8 * cdiv(Tq, 64)), 256, 0, s>>>(p);
 }
 
 void launch_attn_cross(const float* q_slab, int q_ksplit, int q_m_pad, const float* q_bias, float q_scale, const half_t* kp,
                        const half_t* vp, int n_audio, int G, int T, int H, half_t* out, hipStream_t s) {
     WRS_REQUIRE(G >= 1 && G <= 16, "attn_cross: group size %d not in 1..16", G);
     WRS_REQUIRE(T >= 1 && q_slab && q_bias && q_ksplit >= 1, "attn_cross: bad argument");
-    AttnParams p{nullptr, 0, kp, vp, T, (int)round_up(T, 32), H, G, G, out, 0, q_slab, q_ksplit, q_m_pad, q_bias, q_scale};
+    AttnParams p{nullptr, 0, kp, vp, T, (int)round_up(T, 32), H, G, G, out, 0, q_slab, q_ksplit, q_m_pad, q_bias, q_scale, 0};
     dim3 grid(1, (unsigned)H, (unsigned)n_audio);
     attn_mfma_kernel<true><<<grid, 256, 0, s>>>(p);
 }
