@@ -431,6 +431,9 @@ void launch_gemm_skinny(const half_t* a, const half_t* w_packed, int M, int64_t 
 //     (conflict-free ds_read_b128);
 //   * partial sums go to slab[blockIdx.y] with one 16-byte store per lane per row tile; the consumer kernel
 //     reduces the slabs in fixed order (deterministic, unlike float atomics).
+#ifndef DEC_W_AUX
+#define DEC_W_AUX 0  // cache policy of the weight stream's direct-to-LDS loads (2 = non-temporal)
+#endif
 template <int MT, int KPS>
 __global__ __launch_bounds__(256) void gemm_dec_kernel(const half_t* __restrict__ a, const half_t* __restrict__ wp,
                                                        float* __restrict__ slab, int M, int N, int ksteps, int m_pad) {
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(const half_t* __restrict_
 #pragma unroll
     for (int i = 0; i < KPS; ++i)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + (int64_t)i * 512),
-                                         (__attribute__((address_space(3))) void*)(wlds + (size_t)(wave * KPS + i) * 64), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(wlds + (size_t)(wave * KPS + i) * 64), 16, 0, DEC_W_AUX);
     // row tile mt is fetched by wave (mt & 3): KPS contiguous KiB per row tile in the packed activation layout
     for (int mt = wave; mt < MT; mt += 4) {
         const half_t* src = a + ((int64_t)(mt0 + mt) * ksteps + ks0) * 512 + lane * 8;
