@@ -104,6 +104,7 @@ struct GemmParams {
     int64_t ldc, c_rpb, c_brows, c_roff;
 };
 
+template <bool APACKED>  // APACKED: A is in packed-activation (fragment) order, as produced by the decode-step kernels
 __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
     // [buf][0 = activations, 1 = weights][fragment][lane] ; 2*2*16*64*16 B = 64 KiB
     __shared__ half8 lds[2][2][16][64];
@@ -123,14 +124,25 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
     const int r = seq - band * 8 * nt_n;
     const int m0 = (band_m0 + r % band_rows) * 128, n0 = (r / band_rows) * 128;
 
+    // Activation tile: 128 rows x 64 halfs (one 128-B line per row per k-tile).  Each wave instruction fetches 8 FULL
+    // rows (lane -> row l/8, 16-B chunk l%8): whole cache lines instead of 16 half lines.  LDS image is row-major
+    // [128][128 B]; to keep the fragment reads (16 rows x one chunk per ds_read_b128) conflict-free the chunk index is
+    // XOR-swizzled with (row >> 1) & 7 — on the SOURCE address (the direct-to-LDS destination is always lane-linear)
+    // and again on the read.  Weight tile: fragment-packed in HBM, lane-linear as before.
     const half_t* a_ptr[4];
     const half_t* w_ptr[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int f = wave * 4 + j, t16 = f >> 1, ks = f & 1;
-        int64_t m = m0 + t16 * 16 + (lane & 15);
-        if (m > p.M - 1) m = p.M - 1;
-        a_ptr[j] = p.a + (m / p.a_rpb) * p.a_bs + (m % p.a_rpb) * p.lda + ks * 32 + (lane >> 4) * 8;
+        if (APACKED) {  // fragment (row tile, k-step) is 1 KiB contiguous: lane-linear, LDS image fragment-ordered
+            a_ptr[j] = p.a + ((int64_t)(m0 / 16 + t16) * p.ksteps + ks) * 512 + lane * 8;
+        } else {
+            const int rl = (wave * 4 + j) * 8 + (lane >> 3);       // row within the tile
+            const int chunk = (lane & 7) ^ ((rl >> 1) & 7);         // global 16-B chunk stored at LDS chunk (lane & 7)
+            int64_t m = m0 + rl;
+            if (m > p.M - 1) m = p.M - 1;
+            a_ptr[j] = p.a + (m / p.a_rpb) * p.a_bs + (m % p.a_rpb) * p.lda + chunk * 8;
+        }
         w_ptr[j] = p.wp + ((int64_t)(n0 / 16 + t16) * p.ksteps + ks) * 512 + lane * 8;
     }
 
@@ -142,53 +154,104 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
 
     const int wy = wave >> 1, wx = wave & 1;
     const int nk = p.K / 64;
-    half8 ra[4], rw[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        ra[j] = *reinterpret_cast<const half8*>(a_ptr[j]);
-        rw[j] = *reinterpret_cast<const half8*>(w_ptr[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        lds[0][0][wave * 4 + j][lane] = ra[j];
-        lds[0][1][wave * 4 + j][lane] = rw[j];
-    }
+    // Operand staging by direct-to-LDS loads (global_load_lds_dwordx4): the LDS image is fragment-ordered, so the
+    // wave-uniform-base + lane*16 destination rule is exactly one fragment per instruction; the per-lane SOURCE
+    // address does the gather for the row-major activation operand.  No staging VGPRs, no ds_write pass.
+    // Tile kt+1 is requested before the MFMAs of tile kt and waited for (vmcnt(0)) right before the barrier.
+#define WRS_STAGE(buf_, kt_)                                                                                                   \
+    do {                                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[j] + (int64_t)(kt_) * (APACKED ? 1024 : 64)),  \
+                                             (__attribute__((address_space(3))) void*)&lds[buf_][0][wave * 4 + j][0], 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[j] + (int64_t)(kt_) * 1024), \
+                                             (__attribute__((address_space(3))) void*)&lds[buf_][1][wave * 4 + j][0], 16, 0, 0); \
+        }                                                                                                                      \
+    } while (0)
+    WRS_STAGE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ra[j] = *reinterpret_cast<const half8*>(a_ptr[j] + (int64_t)(kt + 1) * 64);
-                rw[j] = *reinterpret_cast<const half8*>(w_ptr[j] + (int64_t)(kt + 1) * 1024);
-            }
-        }
+        if (kt + 1 < nk) WRS_STAGE(buf ^ 1, kt + 1);
+        // all 16 fragment reads of the k-tile are issued before its 32 MFMAs: LDS latency is exposed once per
+        // k-tile (the compiler's own schedule drained lgkmcnt four times with 4 MFMAs in between)
+        half8 wf[2][4], af[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            half8 wf[4], af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = lds[buf][1][(wy * 4 + i) * 2 + ks][lane];
+            for (int i = 0; i < 4; ++i) wf[ks][i] = lds[buf][1][(wy * 4 + i) * 2 + ks][lane];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = lds[buf][0][(wx * 4 + j) * 2 + ks][lane];
+            for (int j = 0; j < 4; ++j) {
+                if (APACKED) {
+                    af[ks][j] = lds[buf][0][(wx * 4 + j) * 2 + ks][lane];
+                } else {
+                    const int r = wx * 64 + j * 16 + (lane & 15);
+                    const int q = (ks * 4 + (lane >> 4)) ^ ((r >> 1) & 7);
+                    af[ks][j] = (&lds[buf][0][0][0])[r * 8 + q];  // row r = 8 x 16-B chunks
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                lds[buf ^ 1][0][wave * 4 + j][lane] = ra[j];
-                lds[buf ^ 1][1][wave * 4 + j][lane] = rw[j];
-            }
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+#undef WRS_STAGE
 
-    // epilogue
+    // epilogue.  Vector path (N, ldc multiples of 4: every shape of the model except an odd vocabulary): all
+    // bias / positional / residual accesses are 16-byte loads requested together, branches are wave-uniform.
     const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0);
+    const int ncol0 = n0 + wy * 64 + 4 * (lane >> 4);
+    if (vec_ok) {
+        floatx4 bias4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = ncol0 + i * 16;
+            bias4[i] = (p.bias && n < p.N) ? *reinterpret_cast<const floatx4*>(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = m0 + wx * 64 + j * 16 + (lane & 15);
+            const bool mok = m < p.M;
+            const int64_t mc = mok ? m : p.M - 1;
+            const int64_t mb = mc / p.c_rpb, mr = mc % p.c_rpb;
+            const int64_t crow = mb * p.c_brows + mr + p.c_roff;
+            floatx4 pos4[4], res4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = ncol0 + i * 16;
+                const bool ok = mok && n < p.N;
+                pos4[i] = (p.posemb && ok) ? *reinterpret_cast<const floatx4*>(p.posemb + mr * p.N + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+                res4[i] = (p.residual && ok) ? *reinterpret_cast<const floatx4*>(p.residual + crow * p.ldc + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = ncol0 + i * 16;
+                if (!(mok && n < p.N)) continue;
+                floatx4 v = acc[i][j] + bias4[i];
+                if (n < p.scale_n_end) v *= p.scale;  // scale_n_end is a multiple of 4
+                if (p.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
+                }
+                v += pos4[i];
+                v += res4[i];
+                if (p.c_f32) *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.c) + crow * p.ldc + n) = v;
+                else *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.c) + crow * p.ldc + n) =
+                        half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t m = m0 + wx * 64 + j * 16 + (lane & 15);
@@ -197,37 +260,19 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
         const int64_t crow = mb * p.c_brows + mr + p.c_roff;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wy * 64 + i * 16 + 4 * (lane >> 4);
-            if (n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            const int n = ncol0 + i * 16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int nn = n + r;
                 if (nn < p.N) {
-                    float x = v[r];
+                    float x = acc[i][j][r];
                     if (p.bias) x += p.bias[nn];
                     if (nn < p.scale_n_end) x *= p.scale;
                     if (p.act) x = gelu_exact(x);
                     if (p.posemb) x += p.posemb[mr * p.N + nn];
                     if (p.residual) x += p.residual[crow * p.ldc + nn];
-                    v[r] = x;
-                }
-            }
-            if (vec_ok) {
-                if (p.c_f32) {
-                    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.c) + crow * p.ldc + n) =
-                        floatx4{v[0], v[1], v[2], v[3]};
-                } else {
-                    *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.c) + crow * p.ldc + n) =
-                        half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r < p.N) {
-                        if (p.c_f32) reinterpret_cast<float*>(p.c)[crow * p.ldc + n + r] = v[r];
-                        else reinterpret_cast<half_t*>(p.c)[crow * p.ldc + n + r] = (_Float16)v[r];
-                    }
+                    if (p.c_f32) reinterpret_cast<float*>(p.c)[crow * p.ldc + nn] = x;
+                    else reinterpret_cast<half_t*>(p.c)[crow * p.ldc + nn] = (_Float16)x;
                 }
             }
         }
@@ -237,8 +282,9 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
 void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t N, int64_t K, const GemmEpi& e,
                      hipStream_t s) {
     WRS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_f16: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
-    WRS_REQUIRE(A.lda % 8 == 0 && A.batch_stride % 8 == 0, "gemm_f16: A strides must be multiples of 8 halfs");
+    WRS_REQUIRE(A.packed || (A.lda % 8 == 0 && A.batch_stride % 8 == 0), "gemm_f16: A strides must be multiples of 8 halfs");
     WRS_REQUIRE(M < (1ll << 31) && N < (1ll << 31), "gemm_f16: shape too large");
+    WRS_REQUIRE(e.scale_n_end % 4 == 0, "gemm_f16: scale_n_end must be a multiple of 4");
     GemmParams p;
     p.a = A.a; p.lda = A.lda; p.a_rpb = A.rows_per_batch; p.a_bs = A.batch_stride;
     p.wp = w_packed; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ksteps = (int)(K / 32);
@@ -246,7 +292,12 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     p.residual = e.residual; p.posemb = e.posemb; p.c = e.c; p.c_f32 = e.c_f32; p.ldc = e.ldc;
     p.c_rpb = e.c_rows_per_batch; p.c_brows = e.c_batch_rows; p.c_roff = e.c_row_off;
     const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);
-    gemm_f16_kernel<<<(unsigned)(8 * cdiv(tiles, 8)), 256, 0, s>>>(p);
+    if (A.packed) {
+        WRS_REQUIRE(A.packed_rows >= round_up(M, 128), "gemm_f16: packed A must hold a multiple of 128 rows (%ld < %ld)", (long)A.packed_rows, (long)round_up(M, 128));
+        gemm_f16_kernel<true><<<(unsigned)(8 * cdiv(tiles, 8)), 256, 0, s>>>(p);
+    } else {
+        gemm_f16_kernel<false><<<(unsigned)(8 * cdiv(tiles, 8)), 256, 0, s>>>(p);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ skinny GEMM
@@ -274,6 +325,7 @@ int skinny_m_pad(int M) {
     static const int opts[] = {1, 2, 4, 6, 8, 10, 12, 16, 20};
     for (int o : opts)
         if (o * 16 >= M) return o * 16;
+    if (M <= 1280) return (M + 159) / 160 * 160;  // beyond 320 rows: multiples of 10 row tiles (row blocks)
     return -1;
 }
 
@@ -390,10 +442,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
     }
 }
 
-void launch_gemm_skinny(const half_t* a, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K, int ksplit,
-                        const SkinnyEpi& e, hipStream_t s) {
+static void launch_gemm_skinny_block(const half_t* a, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K, int ksplit,
+                                     const SkinnyEpi& e, hipStream_t s) {
     const int m_pad = skinny_m_pad(M);
-    WRS_REQUIRE(m_pad > 0, "gemm_skinny: M=%d exceeds 320 rows", M);
+    WRS_REQUIRE(m_pad > 0 && m_pad <= 320, "gemm_skinny: M=%d exceeds 320 rows per block", M);
     WRS_REQUIRE(K % 32 == 0 && n_pad % 32 == 0 && N <= n_pad, "gemm_skinny: bad shape N=%ld n_pad=%ld K=%ld", (long)N,
                 (long)n_pad, (long)K);
     WRS_REQUIRE(ksplit >= 1 && (K / 32) % ksplit == 0, "gemm_skinny: ksplit %d does not divide K/32=%ld", ksplit, (long)(K / 32));
@@ -415,6 +467,18 @@ void launch_gemm_skinny(const half_t* a, const half_t* w_packed, int M, int64_t 
         WRS_SK(1) WRS_SK(2) WRS_SK(4) WRS_SK(6) WRS_SK(8) WRS_SK(10) WRS_SK(12) WRS_SK(16) WRS_SK(20)
 #undef WRS_SK
         default: WRS_THROW(WRS_EINVAL, "gemm_skinny: unsupported m_pad %d", m_pad);
+    }
+}
+
+// More than 320 rows: row blocks of 320 (only the row-major fp32 epilogue used by the logits GEMM supports this)
+void launch_gemm_skinny(const half_t* a, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K, int ksplit,
+                        const SkinnyEpi& e, hipStream_t s) {
+    if (M <= 320) { launch_gemm_skinny_block(a, w_packed, M, N, n_pad, K, ksplit, e, s); return; }
+    WRS_REQUIRE(e.kind == SK_F32 && ksplit == 1, "gemm_skinny: > 320 rows only with the fp32 row-major epilogue");
+    for (int m0 = 0; m0 < M; m0 += 320) {
+        SkinnyEpi eb = e;
+        eb.c = reinterpret_cast<float*>(e.c) + (int64_t)m0 * e.ldc;
+        launch_gemm_skinny_block(a + (int64_t)(m0 / 16) * (K / 32) * 512, w_packed, std::min(320, M - m0), N, n_pad, K, 1, eb, s);
     }
 }
 
@@ -548,7 +612,7 @@ static void launch_dec_k(int kps, const half_t* a, const half_t* wp, float* slab
 
 void launch_gemm_dec(const half_t* a, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K, float* slab, hipStream_t s) {
     const int m_pad = skinny_m_pad(M);
-    WRS_REQUIRE(m_pad > 0, "gemm_dec: M=%d exceeds 320 rows", M);
+    WRS_REQUIRE(m_pad > 0, "gemm_dec: M=%d exceeds 1280 rows", M);
     WRS_REQUIRE(K % 32 == 0 && n_pad % 64 == 0 && N <= n_pad && N % 4 == 0, "gemm_dec: bad shape N=%ld n_pad=%ld K=%ld", (long)N, (long)n_pad, (long)K);
     int kps = 0, mt = 0;
     gemm_dec_plan(M, N, K, &kps, &mt);

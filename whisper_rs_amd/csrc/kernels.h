@@ -58,6 +58,8 @@ struct GemmA {
     int64_t lda = 0;                       // halfs between consecutive rows (may be < K: overlapping rows)
     int64_t rows_per_batch = 1ll << 40;    // A row of m = a + (m / rpb) * batch_stride + (m % rpb) * lda
     int64_t batch_stride = 0;
+    int packed = 0;                        // 1: A is in packed-activation order (pa_off), K/32 k-steps per row tile
+    int64_t packed_rows = 0;               // rows the packed buffer holds (multiple of 16; must cover round_up(M, 128))
 };
 // C[M, N] = A[M, K] * W[N, K]^T ; K multiple of 64; W packed with n_pad multiple of 128
 void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t N, int64_t K, const GemmEpi& epi,
