@@ -96,9 +96,9 @@ def window_seed(rank):
 
 def max_over_ranks(elapsed, world, device):
     """timed-region length of the job = the slowest rank's (all_reduce MAX; the only collective in the bench)."""
-    if world <= 1:
-        return elapsed
     import torch.distributed as dist
+    if world <= 1 and not (dist.is_available() and dist.is_initialized()):
+        return elapsed
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v2")
-    ap.add_argument("--batch", type=int, default=32, help="30-s windows per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="30-s windows per step per GPU (independent units; 256 x beam 5 = 1280 decoder rows)")
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--sample-len", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,8 +129,10 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("WRS_BENCH_FORCE_DIST") == "1"
+    if use_dist:  # launched by torch.distributed.run: one rank per GPU, RCCL only for barrier + MAX
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
     import whisper_rs_amd as W
@@ -150,7 +152,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -220,7 +222,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(dims, args.beam, args.sample_len)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -219,3 +219,16 @@ def test_teacher_forced_steps_vs_oracle(gpu, dims_name, n_audio, sample_len):
 
 def test_teacher_forced_with_early_eot(gpu):
     _teacher_forced_check(gpu, "micro", 2, 40, 0.8, force_eot_after=12)
+
+
+def test_large_batch_gemm_path_teacher_forced(gpu, monkeypatch):
+    """decode steps with many rows (>= 480) run their GEMMs on the tiled kernel instead of the split-K one;
+    force that path at test size and hold it to the same teacher-forced bar."""
+    import helpers
+    monkeypatch.setenv("WRS_DEC_BIG_GEMM_ROWS", "1")
+    helpers._gpu_models.pop(("micro", 0, ()), None)  # the threshold is read when a decoder state is created
+    try:
+        _teacher_forced_check(gpu, "micro", 2, 32, 0.85)
+    finally:
+        monkeypatch.delenv("WRS_DEC_BIG_GEMM_ROWS")
+        helpers._gpu_models.pop(("micro", 0, ()), None)

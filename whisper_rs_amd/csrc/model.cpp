@@ -417,10 +417,11 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.kc.alloc((size_t)L_dec * r_cap * n_ctx * D * 2);
     st.vc.alloc((size_t)L_dec * r_cap * n_ctx * D * 2);
     st.anc.alloc((size_t)2 * r_cap * n_ctx * 4);
+    st.act_rows = (int)round_up(m_pad, 128);  // packed activations are also read in 128-row tiles by the big GEMM
     st.x.alloc((size_t)m_pad * D * 4);
-    st.xn.alloc((size_t)m_pad * D * 2);
-    st.att.alloc((size_t)m_pad * D * 2);
-    st.h.alloc((size_t)m_pad * 4 * D * 2);
+    st.xn.alloc((size_t)st.act_rows * D * 2);
+    st.att.alloc((size_t)st.act_rows * D * 2);
+    st.h.alloc((size_t)st.act_rows * 4 * D * 2);
     st.slab.alloc((size_t)40 * m_pad * 4 * D * 4);  // ksplit (<= K/32 <= 40 for N = 4D; <= 160 for N = D) * m_pad * N floats
     st.logits.alloc((size_t)r_cap * V * 4);
     st.ckv_tmp.alloc((size_t)a_cap * T * 2 * D * 2);
@@ -431,6 +432,7 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.parity = 0;
     st.n_audio = 0;
     st.pending_src.clear();
+    if (const char* e = getenv("WRS_DEC_BIG_GEMM_ROWS")) dec_big_gemm_rows = atoi(e);
 }
 
 void Model::load_cross_kv(DecState& st, const half_t* xa16, int n_audio) {
@@ -479,14 +481,25 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     const size_t cross_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
     const int n_audio = rows / q_per_audio;
     const double wD = (double)D * D * 2;  // bytes of a [D, D] fp16 matrix
-    const int ks_qkv = gemm_dec_plan(rows, 3 * D, D, nullptr, nullptr), ks_d = gemm_dec_plan(rows, D, D, nullptr, nullptr),
-              ks_m1 = gemm_dec_plan(rows, 4 * D, D, nullptr, nullptr), ks_m2 = gemm_dec_plan(rows, D, 4 * (int64_t)D, nullptr, nullptr);
+    int ks_qkv = gemm_dec_plan(rows, 3 * D, D, nullptr, nullptr), ks_d = gemm_dec_plan(rows, D, D, nullptr, nullptr),
+        ks_m1 = gemm_dec_plan(rows, 4 * D, D, nullptr, nullptr), ks_m2 = gemm_dec_plan(rows, D, 4 * (int64_t)D, nullptr, nullptr);
     const int mp = st.m_pad_for(rows);
     float* slab = st.slab.as<float>();
-    auto gemm_slab = [&](const char* name, const half_t* a, const half_t* w, int64_t N, int64_t K, int ks, double bytes) {
+    // Few rows: latency-optimised split-K kernel (slabs).  Many rows (>= big_rows): the step's GEMMs are MFMA/L2-bound
+    // like the encoder's, so the 128x128 tiled kernel runs them (packed-A mode) and writes ONE fp32 slab.
+    const bool big = rows >= dec_big_gemm_rows;
+    auto gemm_slab = [&](const char* name, const half_t* a, const half_t* w, int64_t N, int64_t K, int& ks, double bytes) {
         Timed tm(timer, name, stream, bytes);
-        (void)ks;
-        launch_gemm_dec(a, w, rows, N, round_up(N, 128), K, slab, stream);
+        if (big) {
+            GemmA A;
+            A.a = a; A.packed = 1; A.packed_rows = st.act_rows;
+            GemmEpi e;
+            e.c = slab; e.c_f32 = 1; e.ldc = N;
+            launch_gemm_f16(A, w, rows, N, K, e, stream);
+            ks = 1;
+        } else {
+            launch_gemm_dec(a, w, rows, N, round_up(N, 128), K, slab, stream);
+        }
     };
 
     if (update_anc) {

@@ -34,7 +34,7 @@ struct EncoderWorkspace {
 
 // decoder K/V caches + per-step scratch for up to `a_cap` audios x `group` rows
 struct DecState {
-    int a_cap = 0, group = 1, r_cap = 0, m_pad = 0;
+    int a_cap = 0, group = 1, r_cap = 0, m_pad = 0, act_rows = 0;
     int n_audio = 0;  // audios whose cross K/V are loaded
     DevBuf cross_kp, cross_vp;  // [L][a_cap][H][Tp*64]
     DevBuf kc, vc;              // [L][r_cap][n_ctx][D]
@@ -95,6 +95,7 @@ struct Model {
     std::unique_ptr<DecState> stage_state;  // used by the stage API (wrs_decoder_forward)
     StageTimer* timer = nullptr;            // optional per-kernel timing sink
     int debug_enc_stop = 0;                 // debug: stop the encoder after N launches
+    int dec_big_gemm_rows = 1100;           // decode steps with at least this many rows use the tiled GEMM (env WRS_DEC_BIG_GEMM_ROWS)
     // live timing of the dominant decode kernel (cross-attention) with HIP events on this stream: every
     // `cross_ev_every`-th decode step is launched eagerly (not from the graph) with event pairs around the
     // kernel in every `cross_ev_stride`-th layer; all other steps replay the captured graph untouched
