@@ -332,6 +332,7 @@ struct SelfAttnParams {
     int n_ctx, n_rows, phys_mul, H, D;
     const StepParams* sp;
     half_t* out;  // packed activation order
+    int rows_per_audio;  // beams of one audio are consecutive rows and share most of their cached history
 };
 
 __device__ __forceinline__ void slab_chunk8(const float* __restrict__ slab, int ksplit, int64_t slab_stride, int64_t off,
@@ -354,8 +355,14 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
     // one workgroup = (up to) 4 heads of ONE row, so the row's ancestry entries are fetched once
     __shared__ int anc_s[512];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int hpb = (p.H + 3) >> 2;                 // workgroups per row
-    const int row = blockIdx.x / hpb, h = (blockIdx.x % hpb) * 4 + wave;
+    const int hpb = (p.H + 3) >> 2;                 // head groups per row
+    // XCD-aware order: the G beams of one (audio, head group) run back-to-back on ONE XCD, so the K/V rows they
+    // share through the ancestry table (common beam prefixes) are fetched into that L2 once.  Speed only.
+    const int G = p.rows_per_audio;
+    const int j = (int)(blockIdx.x >> 3);
+    const int unit = (j / G) * 8 + (int)(blockIdx.x & 7);  // (audio, head group)
+    if (unit >= (p.n_rows / G) * hpb) return;               // whole workgroup, before any barrier
+    const int row = (unit / hpb) * G + j % G, h = (unit % hpb) * 4 + wave;
     const int g = lane >> 3, c = lane & 7;
     const int D = p.D;
     const int cpos = p.sp->cache_pos;  // the new token's slot; cached positions are 0..cpos-1
@@ -467,11 +474,13 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
 }
 
 void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc,
-                      const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, int phys_mul, int H, int D,
+                      const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, int rows_per_audio, int phys_mul, int H, int D,
                       const StepParams* sp, half_t* out, hipStream_t s) {
     WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && qkv_slab && qkv_bias && ksplit >= 1, "attn_self: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
-    SelfAttnParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out};
-    const unsigned grid = (unsigned)(n_rows * ((H + 3) / 4));
+    WRS_REQUIRE(rows_per_audio >= 1 && n_rows % rows_per_audio == 0, "attn_self: rows %d not a multiple of %d", n_rows, rows_per_audio);
+    SelfAttnParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio};
+    const int64_t units = (int64_t)(n_rows / rows_per_audio) * ((H + 3) / 4);
+    const unsigned grid = (unsigned)(8 * cdiv(units, 8) * rows_per_audio);
     attn_self_kernel<<<grid, 256, 0, s>>>(p);
 }
 

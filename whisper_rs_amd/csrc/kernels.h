@@ -142,7 +142,7 @@ void launch_attn_cross(const float* q_slab, int q_ksplit, int q_m_pad, const flo
 // order.  q/k/v of the new token come from the QKV projection's split-K slabs [ksplit][m_pad][3D]; k/v are appended
 // to kc/vc [phys_row][n_ctx][D] at sp->cache_pos.
 void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc,
-                      const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, int phys_mul, int H, int D,
+                      const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, int rows_per_audio, int phys_mul, int H, int D,
                       const StepParams* sp, half_t* out, hipStream_t s);
 void launch_anc_init(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_phys_rows, int G, hipStream_t s);
 void launch_anc_update(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, const StepParams* sp,

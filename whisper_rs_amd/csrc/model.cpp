@@ -518,7 +518,7 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
         {
             Timed tm(timer, "dec_attn_self", stream);
             launch_attn_self(slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer,
-                             st.anc.as<int>(), anc_stride, n_ctx, rows, phys_mul, H, D, sp, st.att.as<half_t>(), stream);
+                             st.anc.as<int>(), anc_stride, n_ctx, rows, q_per_audio, phys_mul, H, D, sp, st.att.as<half_t>(), stream);
         }
         gemm_slab("dec_gemm_out", st.att.as<half_t>(), b.out_w, D, D, ks_d, wD);
         {
