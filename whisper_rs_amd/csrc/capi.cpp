@@ -118,7 +118,7 @@ int wrs_decoder_forward(wrs_model* h, const int64_t* tokens, int n_batch, int n_
             }
             HIP_CHECK(hipMemcpyAsync(st.sp_dev.p, st.sp_host.p, st.sp_bytes(), hipMemcpyHostToDevice, m.stream));
             m.decoder_step(st, n_batch, 1, 1, true, true);
-            HIP_CHECK(hipMemcpy2DAsync(logits + (size_t)t * m.V, (size_t)n_tokens * m.V * 4, st.logits.p, (size_t)m.V * 4, (size_t)m.V * 4,
+            HIP_CHECK(hipMemcpy2DAsync(logits + (size_t)t * m.V, (size_t)n_tokens * m.V * 4, st.logits.p, (size_t)st.logits_ld * 4, (size_t)m.V * 4,
                                        n_batch, hipMemcpyDeviceToHost, m.stream));
             HIP_CHECK(hipStreamSynchronize(m.stream));
             if (t == 0) st.pending_src.clear();
@@ -282,7 +282,7 @@ int wrs_filter_topk(wrs_decode_task* t, const float* logits, const int64_t* toke
         WRS_REQUIRE(n_rows >= 1 && n_rows <= st.r_cap, "wrs_filter_topk: %d rows exceed capacity %d", n_rows, st.r_cap);
         WRS_REQUIRE(k >= 1 && k <= 8 && n_tokens >= sample_begin && sample_begin >= 0, "wrs_filter_topk: bad k / token counts");
         m.use();
-        HIP_CHECK(hipMemcpyAsync(st.logits.p, logits, (size_t)n_rows * m.V * 4, hipMemcpyHostToDevice, m.stream));
+        HIP_CHECK(hipMemcpy2DAsync(st.logits.p, (size_t)st.logits_ld * 4, logits, (size_t)m.V * 4, (size_t)m.V * 4, n_rows, hipMemcpyHostToDevice, m.stream));
         StepParams* sp = st.sp_h();
         memset(sp, 0, sizeof(*sp));
         sp->first_step = (n_tokens == sample_begin) ? 1 : 0;

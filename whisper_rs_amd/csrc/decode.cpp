@@ -89,6 +89,7 @@ void DecodeTask::set_prompt(const int64_t* p, int n) {  // decode/mod.rs:46-92,2
 FilterCfg DecodeTask::filter_cfg() const {
     FilterCfg c;
     c.n_vocab = m->V;
+    c.ld = st.logits_ld;
     c.ts_begin = ids.ts_begin; c.eot = ids.eot; c.no_timestamps = ids.no_timestamps; c.no_speech = ids.no_speech;
     c.space = ids.space;
     c.suppress_blank = suppress_blank ? 1 : 0;

@@ -102,6 +102,7 @@ struct GemmParams {
     void* c;
     int c_f32;
     int64_t ldc, c_rpb, c_brows, c_roff;
+    int c_packed;
 };
 
 template <bool APACKED>  // APACKED: A is in packed-activation (fragment) order, as produced by the decode-step kernels
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
                 v += pos4[i];
                 v += res4[i];
                 if (p.c_f32) *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.c) + crow * p.ldc + n) = v;
-                else *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.c) + crow * p.ldc + n) =
+                else *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.c) + (p.c_packed ? pa_off((int)crow, n, p.N >> 5) : crow * p.ldc + n)) =
                         half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             }
         }
@@ -290,7 +291,8 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     p.wp = w_packed; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ksteps = (int)(K / 32);
     p.bias = e.bias; p.scale = e.scale; p.scale_n_end = e.scale_n_end; p.act = e.act;
     p.residual = e.residual; p.posemb = e.posemb; p.c = e.c; p.c_f32 = e.c_f32; p.ldc = e.ldc;
-    p.c_rpb = e.c_rows_per_batch; p.c_brows = e.c_batch_rows; p.c_roff = e.c_row_off;
+    p.c_rpb = e.c_rows_per_batch; p.c_brows = e.c_batch_rows; p.c_roff = e.c_row_off; p.c_packed = e.c_packed;
+    if (e.c_packed) WRS_REQUIRE(!e.c_f32 && N % 32 == 0 && e.ldc % 4 == 0, "gemm_f16: packed output needs fp16 and N %% 32 == 0");
     const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);
     if (A.packed) {
         WRS_REQUIRE(A.packed_rows >= round_up(M, 128), "gemm_f16: packed A must hold a multiple of 128 rows (%ld < %ld)", (long)A.packed_rows, (long)round_up(M, 128));

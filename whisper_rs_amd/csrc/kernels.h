@@ -52,6 +52,7 @@ struct GemmEpi {
     int64_t c_rows_per_batch = 1ll << 40;  // C row of m = (m / rpb) * c_batch_rows + m % rpb + c_row_off
     int64_t c_batch_rows = 0;
     int64_t c_row_off = 0;
+    int c_packed = 0;                      // fp16 output in packed-activation order (pa_off with K' = N) instead of row-major
 };
 struct GemmA {
     const half_t* a = nullptr;
@@ -151,6 +152,7 @@ void launch_anc_update(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_r
 // ---------------------------------------------------------------- logits: filters + log-softmax + top-k
 struct FilterCfg {
     int n_vocab;
+    int ld = 0;                 // floats between logits rows (0: n_vocab)
     int ts_begin, eot, no_timestamps, no_speech, space;
     int suppress_blank;         // SuppressBlank enabled
     int timestamps;             // TimestampTokens enabled

@@ -46,6 +46,7 @@ __device__ __forceinline__ float block_add(float v, float* sh) {
 
 struct FilterParams {
     const float* logits;
+    int ld;
     int n_vocab, ts_begin, eot, no_timestamps, no_speech, space;
     int suppress_blank, timestamps, mit;
     const int* suppress_ids;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
     __shared__ int cand_i[256];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int V = p.n_vocab;
-    const float* x = p.logits + (int64_t)row * V;
+    const float* x = p.logits + (int64_t)row * p.ld;
     const int first = p.sp->first_step;
     const int nwords = (V + 31) / 32;
 
@@ -232,7 +233,7 @@ void launch_filter_topk(const float* logits, int n_rows, const FilterCfg& cfg, c
                     cfg.no_timestamps < cfg.n_vocab && cfg.no_speech < cfg.n_vocab && cfg.space < cfg.n_vocab,
                 "filter_topk: token ids out of range for vocab %d", cfg.n_vocab);
     FilterParams p;
-    p.logits = logits; p.n_vocab = cfg.n_vocab; p.ts_begin = cfg.ts_begin; p.eot = cfg.eot;
+    p.logits = logits; p.ld = cfg.ld > 0 ? cfg.ld : cfg.n_vocab; p.n_vocab = cfg.n_vocab; p.ts_begin = cfg.ts_begin; p.eot = cfg.eot;
     p.no_timestamps = cfg.no_timestamps; p.no_speech = cfg.no_speech; p.space = cfg.space;
     p.suppress_blank = cfg.suppress_blank; p.timestamps = cfg.timestamps; p.mit = cfg.max_initial_ts_index;
     p.suppress_ids = cfg.suppress_ids; p.n_suppress = cfg.n_suppress; p.sp = sp; p.ts_mode = ts_mode; p.k = k;

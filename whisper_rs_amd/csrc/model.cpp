@@ -423,7 +423,8 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.att.alloc((size_t)st.act_rows * D * 2);
     st.h.alloc((size_t)st.act_rows * 4 * D * 2);
     st.slab.alloc((size_t)40 * m_pad * 4 * D * 4);  // ksplit (<= K/32 <= 40 for N = 4D; <= 160 for N = D) * m_pad * N floats
-    st.logits.alloc((size_t)r_cap * V * 4);
+    st.logits_ld = (int)round_up(V, 8);  // row pitch of the logits buffer (16-byte aligned rows for vector stores)
+    st.logits.alloc((size_t)r_cap * st.logits_ld * 4);
     st.ckv_tmp.alloc((size_t)a_cap * T * 2 * D * 2);
     st.sp_dev.alloc(st.sp_bytes());
     st.sp_host.alloc(st.sp_bytes());
@@ -547,8 +548,15 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
                                       st.xn.as<half_t>(), stream);
         }
         // + mlp(mlp_ln(x))   (model.rs:315)
-        gemm_slab("dec_gemm_mlp1", st.xn.as<half_t>(), b.mlp0_w, 4 * D, D, ks_m1, 4 * wD);
-        {
+        if (big) {  // bias + GELU + packed fp16 store in the GEMM epilogue: no slab, no finish kernel
+            Timed tm(timer, "dec_gemm_mlp1", stream, 4 * wD);
+            GemmA A;
+            A.a = st.xn.as<half_t>(); A.packed = 1; A.packed_rows = st.act_rows;
+            GemmEpi e;
+            e.bias = b.mlp0_b; e.act = 1; e.c = st.h.p; e.c_f32 = 0; e.ldc = 4 * D; e.c_packed = 1;
+            launch_gemm_f16(A, b.mlp0_w, rows, 4 * D, D, e, stream);
+        } else {
+            gemm_slab("dec_gemm_mlp1", st.xn.as<half_t>(), b.mlp0_w, 4 * D, D, ks_m1, 4 * wD);
             Timed tm(timer, "dec_finish_gelu", stream);
             launch_finish_act(slab, ks_m1, mp, b.mlp0_b, 1, rows, 4 * D, st.h.as<half_t>(), stream);
         }
@@ -562,9 +570,17 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     }
     if (want_logits) {
         Timed tm(timer, "dec_gemm_logits", stream, (double)V * D * 2 + (double)rows * V * 4);
-        SkinnyEpi e;
-        e.kind = SK_F32; e.c = st.logits.p; e.ldc = V;
-        launch_gemm_skinny(st.xn.as<half_t>(), emb_p, rows, V, v_pad, D, 1, e, stream);
+        if (big) {  // tied output projection on the tiled kernel; logits rows padded to st.logits_ld floats
+            GemmA A;
+            A.a = st.xn.as<half_t>(); A.packed = 1; A.packed_rows = st.act_rows;
+            GemmEpi e;
+            e.c = st.logits.p; e.c_f32 = 1; e.ldc = st.logits_ld;
+            launch_gemm_f16(A, emb_p, rows, st.logits_ld, D, e, stream);  // columns >= V come from zero weight rows
+        } else {
+            SkinnyEpi e;
+            e.kind = SK_F32; e.c = st.logits.p; e.ldc = st.logits_ld;
+            launch_gemm_skinny(st.xn.as<half_t>(), emb_p, rows, V, v_pad, D, 1, e, stream);
+        }
     }
 }
 

@@ -34,7 +34,7 @@ struct EncoderWorkspace {
 
 // decoder K/V caches + per-step scratch for up to `a_cap` audios x `group` rows
 struct DecState {
-    int a_cap = 0, group = 1, r_cap = 0, m_pad = 0, act_rows = 0;
+    int a_cap = 0, group = 1, r_cap = 0, m_pad = 0, act_rows = 0, logits_ld = 0;
     int n_audio = 0;  // audios whose cross K/V are loaded
     DevBuf cross_kp, cross_vp;  // [L][a_cap][H][Tp*64]
     DevBuf kc, vc;              // [L][r_cap][n_ctx][D]
