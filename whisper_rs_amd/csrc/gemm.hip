@@ -103,6 +103,8 @@ struct GemmParams {
     int c_f32;
     int64_t ldc, c_rpb, c_brows, c_roff;
     int c_packed;
+    int ksplit;              // > 1: blockIdx.y = k-slice, fp32 partial sums go to slab blockIdx.y (no epilogue math)
+    int64_t slab_stride;     // floats between slabs
 };
 
 template <bool APACKED>  // APACKED: A is in packed-activation (fragment) order, as produced by the decode-step kernels
@@ -154,7 +156,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int wy = wave >> 1, wx = wave & 1;
-    const int nk = p.K / 64;
+    const int nk = p.K / 64 / p.ksplit;          // k-tiles of this workgroup's slice
+    const int kt0 = blockIdx.y * nk;
     // Operand staging by direct-to-LDS loads (global_load_lds_dwordx4): the LDS image is fragment-ordered, so the
     // wave-uniform-base + lane*16 destination rule is exactly one fragment per instruction; the per-lane SOURCE
     // address does the gather for the row-major activation operand.  No staging VGPRs, no ds_write pass.
@@ -168,12 +171,12 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
                                              (__attribute__((address_space(3))) void*)&lds[buf_][1][wave * 4 + j][0], 16, 0, 0); \
         }                                                                                                                      \
     } while (0)
-    WRS_STAGE(0, 0);
+    WRS_STAGE(0, kt0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) WRS_STAGE(buf ^ 1, kt + 1);
+        if (kt + 1 < nk) WRS_STAGE(buf ^ 1, kt0 + kt + 1);
         // all 16 fragment reads of the k-tile are issued before its 32 MFMAs: LDS latency is exposed once per
         // k-tile (the compiler's own schedule drained lgkmcnt four times with 4 MFMAs in between)
         half8 wf[2][4], af[2][4];
@@ -212,6 +215,20 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
     // bias / positional / residual accesses are 16-byte loads requested together, branches are wave-uniform.
     const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0);
     const int ncol0 = n0 + wy * 64 + 4 * (lane >> 4);
+    if (p.ksplit > 1) {  // split-K: raw partial sums to this slice's slab; the consumer kernel reduces in fixed order
+        float* slab = reinterpret_cast<float*>(p.c) + (int64_t)blockIdx.y * p.slab_stride;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = m0 + wx * 64 + j * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = ncol0 + i * 16;
+                if (n < p.N) *reinterpret_cast<floatx4*>(slab + m * p.ldc + n) = acc[i][j];
+            }
+        }
+        return;
+    }
     if (vec_ok) {
         floatx4 bias4[4];
 #pragma unroll
@@ -294,11 +311,17 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     p.c_rpb = e.c_rows_per_batch; p.c_brows = e.c_batch_rows; p.c_roff = e.c_row_off; p.c_packed = e.c_packed;
     if (e.c_packed) WRS_REQUIRE(!e.c_f32 && N % 32 == 0 && e.ldc % 4 == 0, "gemm_f16: packed output needs fp16 and N %% 32 == 0");
     const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);
+    p.ksplit = e.ksplit > 1 ? e.ksplit : 1;
+    p.slab_stride = e.slab_stride;
+    if (p.ksplit > 1)
+        WRS_REQUIRE((K / 64) % p.ksplit == 0 && e.c_f32 && !e.bias && !e.residual && !e.posemb && !e.act && e.ldc % 4 == 0 && N % 4 == 0 &&
+                        e.slab_stride >= M * e.ldc, "gemm_f16: bad split-K configuration");
+    const dim3 grid((unsigned)(8 * cdiv(tiles, 8)), (unsigned)p.ksplit);
     if (A.packed) {
         WRS_REQUIRE(A.packed_rows >= round_up(M, 128), "gemm_f16: packed A must hold a multiple of 128 rows (%ld < %ld)", (long)A.packed_rows, (long)round_up(M, 128));
-        gemm_f16_kernel<true><<<(unsigned)(8 * cdiv(tiles, 8)), 256, 0, s>>>(p);
+        gemm_f16_kernel<true><<<grid, 256, 0, s>>>(p);
     } else {
-        gemm_f16_kernel<false><<<(unsigned)(8 * cdiv(tiles, 8)), 256, 0, s>>>(p);
+        gemm_f16_kernel<false><<<grid, 256, 0, s>>>(p);
     }
 }
 

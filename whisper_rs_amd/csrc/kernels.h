@@ -53,6 +53,8 @@ struct GemmEpi {
     int64_t c_batch_rows = 0;
     int64_t c_row_off = 0;
     int c_packed = 0;                      // fp16 output in packed-activation order (pa_off with K' = N) instead of row-major
+    int ksplit = 1;                        // > 1: split-K, raw fp32 partial sums to c + slice * slab_stride (no epilogue math)
+    int64_t slab_stride = 0;
 };
 struct GemmA {
     const half_t* a = nullptr;

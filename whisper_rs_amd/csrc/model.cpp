@@ -496,8 +496,13 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
             A.a = a; A.packed = 1; A.packed_rows = st.act_rows;
             GemmEpi e;
             e.c = slab; e.c_f32 = 1; e.ldc = N;
+            // keep >= ~256 workgroups in flight: split K when the tile grid alone is too small (N = D shapes)
+            const int64_t tiles = cdiv(rows, 128) * cdiv(N, 128);
+            int split = 1;
+            while (tiles * split < 256 && (K / 64) % (split * 2) == 0 && K / 64 / (split * 2) >= 10) split *= 2;
+            e.ksplit = split; e.slab_stride = (int64_t)mp * N;
             launch_gemm_f16(A, w, rows, N, K, e, stream);
-            ks = 1;
+            ks = split;
         } else {
             launch_gemm_dec(a, w, rows, N, round_up(N, 128), K, slab, stream);
         }
