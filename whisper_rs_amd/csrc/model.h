@@ -95,7 +95,7 @@ struct Model {
     std::unique_ptr<DecState> stage_state;  // used by the stage API (wrs_decoder_forward)
     StageTimer* timer = nullptr;            // optional per-kernel timing sink
     int debug_enc_stop = 0;                 // debug: stop the encoder after N launches
-    int dec_big_gemm_rows = 1100;           // decode steps with at least this many rows use the tiled GEMM (env WRS_DEC_BIG_GEMM_ROWS)
+    int dec_big_gemm_rows = 480;            // decode steps with at least this many rows use the tiled GEMM (env WRS_DEC_BIG_GEMM_ROWS)
     // live timing of the dominant decode kernel (cross-attention) with HIP events on this stream: every
     // `cross_ev_every`-th decode step is launched eagerly (not from the graph) with event pairs around the
     // kernel in every `cross_ev_stride`-th layer; all other steps replay the captured graph untouched
