@@ -1,0 +1,57 @@
+// Standalone timing of gemm_f16_kernel on large-v2 shapes (random fp16 data).
+//   gemm_f16_bench enc  [windows]   encoder shapes, row-major A, M = windows*1500
+//   gemm_f16_bench dec  [rows]      decode-step shapes, packed A, fp32 slab output (split-K as model.cpp picks it)
+// The ring depth is forced with WRS_GEMM_STAGES=2|3|4 (default: the library's own choice).
+#include "../../whisper_rs_amd/csrc/common.cpp"
+#include "../../whisper_rs_amd/csrc/gemm.hip"
+#include <chrono>
+#include <random>
+#include <cstring>
+using namespace wrs;
+static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int main(int argc, char** argv) {
+    const bool dec = argc > 1 && !strcmp(argv[1], "dec");
+    const int D = 1280;
+    const int64_t M = dec ? (argc > 2 ? atoi(argv[2]) : 1280) : (int64_t)(argc > 2 ? atoi(argv[2]) : 32) * 1500;
+    hipStream_t s; HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct Shape { const char* name; int N, K; bool f32out, res, gelu; int ksplit; };
+    std::vector<Shape> shapes;
+    if (dec) {
+        for (int ks : {1, 2, 4}) shapes.push_back({"d_DxD", D, D, true, false, false, ks});
+        shapes.push_back({"d_qkv", 3 * D, D, true, false, false, 1});
+        shapes.push_back({"d_mlp1", 4 * D, D, false, false, true, 1});
+        for (int ks : {1, 2, 4, 8}) shapes.push_back({"d_mlp2", D, 4 * D, true, false, false, ks});
+        shapes.push_back({"d_logit", 51968, D, true, false, false, 1});
+    } else {
+        shapes = {{"qkv", 3 * D, D, false, false, false, 1}, {"out", D, D, true, true, false, 1}, {"mlp1", 4 * D, D, false, false, true, 1},
+                  {"mlp2", D, 4 * D, true, true, false, 1}, {"longK", D, 16 * D, false, false, false, 1}};
+    }
+    std::mt19937 rng(1);
+    std::vector<_Float16> h((size_t)4 << 20);
+    for (auto& x : h) x = (_Float16)(((int)(rng() % 2001) - 1000) / 1000.0f);
+    auto fill = [&](DevBuf& b) { for (size_t off = 0; off < b.bytes; off += h.size() * 2) HIP_CHECK(hipMemcpy((char*)b.p + off, h.data(), std::min(h.size() * 2, b.bytes - off), hipMemcpyHostToDevice)); };
+    const int reps = dec ? 50 : 4;
+    for (auto& sh : shapes) {
+        DevBuf a, w, c, bias;
+        const int64_t mp = round_up(M, 128);
+        a.alloc((size_t)mp * sh.K * 2 + 4096); fill(a);
+        w.alloc((size_t)round_up(sh.N, 128) * sh.K * 2); fill(w);
+        c.alloc((size_t)mp * sh.N * 4 * sh.ksplit); bias.alloc(sh.N * 4);
+        GemmA A{a.as<half_t>(), sh.K};
+        if (dec) { A.packed = 1; A.packed_rows = mp; }
+        GemmEpi e; e.c = c.p; e.c_f32 = sh.f32out; e.ldc = sh.N;
+        if (sh.ksplit > 1) { e.ksplit = sh.ksplit; e.slab_stride = mp * sh.N; }
+        else { e.bias = bias.as<float>(); e.act = sh.gelu; if (dec && !sh.f32out) e.c_packed = 1; }
+        if (sh.res) e.residual = c.as<float>();
+        double best = 1e30;
+        for (int rep = 0; rep < 4; ++rep) {
+            HIP_CHECK(hipStreamSynchronize(s));
+            const double t0 = now();
+            for (int i = 0; i < reps; ++i) launch_gemm_f16(A, w.as<half_t>(), M, sh.N, sh.K, e, s);
+            HIP_CHECK(hipStreamSynchronize(s));
+            best = std::min(best, (now() - t0) / reps);
+        }
+        printf("%-7s M=%ld N=%d K=%d ksplit=%d: %.1f us, %.0f TFLOP/s\n", sh.name, (long)M, sh.N, sh.K, sh.ksplit, best, 2.0 * M * sh.N * sh.K / best / 1e6);
+    }
+    return 0;
+}
