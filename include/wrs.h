@@ -118,13 +118,46 @@ int wrs_pad_or_trim(const float* x, int64_t rows, int64_t n, int64_t len, float*
 int wrs_log_mel_spectrogram(int device_id, const float* audio, int64_t n_batch, int64_t n_samples,
                             const float* filter, float* out, int mem_kind);
 
-/* ---------------------------------------------------------------- decode (src/decode/) */
+/* ---------------------------------------------------------------- tokenizer (src/tokenize.rs) */
 
 /* special ids of reference `Tokenizer` (tokenize.rs:113-131) */
 typedef struct wrs_token_ids {
     int32_t eot, sot, translate, transcribe, startoflm, startofprev, no_speech, no_timestamps, ts_begin;
     int32_t space; /* tokenizer.encode(" ")[0] (suppress_blanks.rs:22-28) */
 } wrs_token_ids;
+
+/* reference `Tokenizer` (tokenize.rs:111-131): GPT-2 byte-level BPE (`tokenizers::Tokenizer`) + Whisper special ids.
+ * Host-only; usable without a GPU. */
+typedef struct wrs_tokenizer wrs_tokenizer;
+
+/* `Tokenizer::new_from_bytes(Task::Transcribe, bytes)` (tokenize.rs:142-202): bytes = a HuggingFace tokenizer.json
+ * (model BPE, ByteLevel pre-tokenizer), e.g. the reference's tokenizer/gpt2.json.  The 106 Whisper specials are added
+ * after the model vocabulary unless the file already holds them (a multilingual vocabulary then yields OpenAI's layout). */
+int wrs_tokenizer_create_from_bytes(const void* bytes, size_t n_bytes, wrs_tokenizer** out);
+/* `Tokenizer::new_from_file(task, path)` (tokenize.rs:204-207) */
+int wrs_tokenizer_create_from_file(const char* path, wrs_tokenizer** out);
+void wrs_tokenizer_destroy(wrs_tokenizer* t);
+/* the `token_id_*` fields (tokenize.rs:113-131) + encode(" ")[0] */
+int wrs_tokenizer_token_ids(const wrs_tokenizer* t, wrs_token_ids* out);
+/* `tokenizer.encode(text, true)` via Deref (tokenize.rs:314-320; call sites transcribe.rs:131, suppress_blanks.rs:22).
+ * utf8/n_bytes: the text (a Rust &str may hold NUL, so the length is explicit).
+ * Writes up to cap ids; *n = number of ids the text has (call again with a larger buffer if *n > cap). */
+int wrs_tokenizer_encode(const wrs_tokenizer* t, const char* utf8, size_t n_bytes, int32_t* out, int32_t cap, int32_t* n);
+/* `Tokenizer::decode(&tokens)` (tokenize.rs:309-312): skip_special_tokens = false; ids outside the vocabulary
+ * (timestamps) are dropped.  *out_text is library-owned, NUL-terminated UTF-8: release with wrs_string_free.
+ * *out_len (optional) = its byte length, for the odd text that holds a NUL itself. */
+int wrs_tokenizer_decode(const wrs_tokenizer* t, const int64_t* ids, int64_t n, char** out_text, size_t* out_len);
+void wrs_string_free(char* s);
+/* `Tokenizer::non_speech_tokens()` (tokenize.rs:215-307): sorted, duplicates kept, as the reference returns them */
+int wrs_tokenizer_non_speech_tokens(const wrs_tokenizer* t, int32_t* out, int32_t cap, int32_t* n);
+/* `tokenizer.token_to_id(token)` (tokenize.rs:170-197); -1 if absent */
+int32_t wrs_tokenizer_token_to_id(const wrs_tokenizer* t, const char* token);
+/* id of "<|xx|>" for a language code of the reference's LANGUAGES table (tokenize.rs:7-109); -1 if unknown */
+int32_t wrs_tokenizer_language_token(const wrs_tokenizer* t, const char* code);
+/* number of ids the tokenizer knows (model vocabulary + added specials) = ts_begin */
+int32_t wrs_tokenizer_vocab_size(const wrs_tokenizer* t);
+
+/* ---------------------------------------------------------------- decode (src/decode/) */
 
 #define WRS_EXTRACT_GREEDY 0      /* TokenExtractMode::Greedy { group_sze } (extractor/mod.rs:12-16) */
 #define WRS_EXTRACT_BEAM_SEARCH 1 /* TokenExtractMode::BeamSearch { beam_size, patience } */
@@ -148,6 +181,10 @@ typedef struct wrs_decode_options {
     int32_t n_non_speech_tokens;
     int32_t position_offset_quirk;  /* 1 = reference behaviour: decoder offset = loop index (decode/mod.rs:244) */
     int32_t max_audio;              /* capacity: windows decoded per run() call (>=1) */
+    /* `Tokenizer::sequence_sot()` (tokenize.rs:209-213) minus its leading sot: NULL/0 = the reference ([sot]);
+     * OpenAI's multilingual form [sot, <|lang|>, <|transcribe|> or <|translate|>] is given as {lang, task}. */
+    const int32_t* sot_sequence_tail;
+    int32_t n_sot_sequence_tail;
 } wrs_decode_options;
 
 /* reference `DecodeOutput` (decode/mod.rs:109-119); text is produced by the caller's tokenizer */
@@ -158,6 +195,8 @@ typedef struct wrs_decode_output {
     double no_speech_prob;
     double sum_logprob;
     const float* audio_features_device; /* device pointer [n_audio_ctxs, n_audio_states] fp32, valid until the next run */
+    char* text; /* `DecodeOutput.text` = tokenizer.decode(tokens) (decode/mod.rs:404): library-owned UTF-8, NULL unless a
+                 * tokenizer is attached with wrs_decode_task_set_tokenizer */
 } wrs_decode_output;
 
 typedef struct wrs_decode_result {
@@ -171,6 +210,9 @@ typedef struct wrs_decode_task wrs_decode_task;
 /* `DecodeTask::new(&model, tokenizer, options)` (decode/mod.rs:122-204) */
 int wrs_decode_task_create(wrs_model* m, const wrs_token_ids* ids, const wrs_decode_options* opt,
                            wrs_decode_task** out);
+/* `DecodeTask::new` takes the tokenizer as Rc<Tokenizer> (decode/mod.rs:122-126): attach it to have `text` filled in.
+ * Non-owning: the tokenizer must outlive the task.  NULL detaches. */
+int wrs_decode_task_set_tokenizer(wrs_decode_task* t, const wrs_tokenizer* tok);
 /* `DecodeTask::set_prompt(Option<&Tensor>)` (decode/mod.rs:206-218); n==0 or NULL => None */
 int wrs_decode_task_set_prompt(wrs_decode_task* t, const int64_t* prompt, int32_t n);
 /* `DecodeTask::run(&mel)` (decode/mod.rs:284-419).  mel: [n_audio, 80, 3000] f32 (the reference's
@@ -183,6 +225,17 @@ int wrs_decode_task_run_features(wrs_decode_task* t, const float* audio_features
 /* same, starting from raw audio windows [n_audio, 480000] f32: mel (per-window max) + run. */
 int wrs_decode_task_run_audio(wrs_decode_task* t, const float* audio, int32_t n_audio, int mem_kind,
                               wrs_decode_result* result);
+/* same, on the windows whose encoder output is still resident from the previous run / detect call of this task's model */
+int wrs_decode_task_run_encoded(wrs_decode_task* t, int32_t n_audio, wrs_decode_result* result);
+/* Language identification (the reference declares `Task::LanguageId`, tokenize.rs:135-139, without implementing it;
+ * semantics follow OpenAI whisper's detect_language): encoder, one decoder position with <|startoftranscript|>, softmax
+ * over the n_languages ids starting at first_language_id (wrs_tokenizer_language_token(t, "en") ...).
+ *   mel: [n_audio, 80, 3000] f32; out_language_ids: [n_audio]; out_probs: [n_audio, n_languages] or NULL. */
+int wrs_decode_task_detect_language(wrs_decode_task* t, const float* mel, int32_t n_audio, int mem_kind,
+                                    int32_t first_language_id, int32_t n_languages, int32_t* out_language_ids, float* out_probs);
+/* per-window language token for the next runs: replaces sot_sequence_tail[0] for window a with language_ids[a]
+ * (OpenAI decoding.py `tokens[:, sot_index + 1] = lang_tokens`).  n = 0 clears.  Needs n_sot_sequence_tail >= 1. */
+int wrs_decode_task_set_languages(wrs_decode_task* t, const int32_t* language_ids, int32_t n);
 /* per-step trace of the last run (test aid): for step s, row r: chosen token, source row, sum_logprob. */
 int wrs_decode_task_trace(wrs_decode_task* t, int32_t* n_steps, int32_t* n_rows, const int32_t** tokens,
                           const int32_t** sources, const float** sum_logprobs);
@@ -210,11 +263,12 @@ typedef struct wrs_transcribe_options {
     int32_t condition_on_prev_text; /* used when prompt_tokens == NULL */
 } wrs_transcribe_options;
 
-/* reference `TranscribeOutputSegment` (transcribe.rs:59-67), text left to the caller's tokenizer */
+/* reference `TranscribeOutputSegment` (transcribe.rs:59-67) */
 typedef struct wrs_segment {
     int64_t seek;
     double start_time, end_time;
     int64_t start_token, end_token;
+    char* text; /* library-owned UTF-8 (transcribe.rs:200,227); NULL unless a tokenizer is attached */
 } wrs_segment;
 
 typedef struct wrs_transcribe_output {
@@ -227,6 +281,7 @@ typedef struct wrs_transcribe_output {
     double* window_avg_logprob;
     double* window_no_speech_prob;
     int64_t n_windows;
+    char* text; /* `TranscribeOutput.text` = tokenizer.decode(tokens) (transcribe.rs:236); NULL unless a tokenizer is attached */
 } wrs_transcribe_output;
 
 typedef struct wrs_transcribe_task wrs_transcribe_task;
@@ -234,6 +289,10 @@ typedef struct wrs_transcribe_task wrs_transcribe_task;
 /* `TranscribeTask::new(&model, options)` (transcribe.rs:70-101) */
 int wrs_transcribe_task_create(wrs_model* m, const wrs_token_ids* ids, const wrs_transcribe_options* opt,
                                wrs_transcribe_task** out);
+/* `TranscribeOptions.tokenizer` (transcribe.rs:49): attach it to have text / segment text filled in.  Non-owning. */
+int wrs_transcribe_task_set_tokenizer(wrs_transcribe_task* t, const wrs_tokenizer* tok);
+/* `TranscribePrompt::Text(String)` (transcribe.rs:27,130-134): encoded with the attached tokenizer; implies conditioning. */
+int wrs_transcribe_task_set_prompt_text(wrs_transcribe_task* t, const char* utf8);
 /* `TranscribeTask::run(&audio)` (transcribe.rs:103-243): the sequential long-form loop. audio [n] f32 host. */
 int wrs_transcribe_task_run(wrs_transcribe_task* t, const float* audio, int64_t n_samples, wrs_transcribe_output* out);
 /* fixed-stride variant (= the reference's `seek += N_FRAMES` branch with conditioning off,

@@ -41,8 +41,9 @@ class TokenIds:
 class DecodePrompt:
     """decode/mod.rs:46-92."""
 
-    def __init__(self, prompt: Optional[torch.Tensor], ids: TokenIds):
-        seq_sot = [ids.sot]  # tokenize.rs:201-205 sequence_sot() == [sot]
+    def __init__(self, prompt: Optional[torch.Tensor], ids: TokenIds, sot_tail=()):
+        # tokenize.rs:209-213 sequence_sot() == [sot]; sot_tail = OpenAI's multilingual [lang, task] (not in the reference)
+        seq_sot = [ids.sot] + list(sot_tail)
         if prompt is not None:
             initial = torch.cat([torch.tensor([ids.startofprev], dtype=torch.int64), prompt.to(torch.int64),
                                  torch.tensor(seq_sot, dtype=torch.int64)])
@@ -271,6 +272,7 @@ class DecodeOptions:
     prompt: Optional[torch.Tensor] = None
     non_speech_tokens: tuple = ()
     position_offset_quirk: bool = True  # decoder offset = loop index i (decode/mod.rs:244)
+    sot_sequence_tail: tuple = ()       # beyond the reference: OpenAI's [lang, task] after sot (BASELINE config 4)
 
 
 @dataclass
@@ -294,7 +296,8 @@ class DecodeTask:
         else:
             self.extractor = BeamSearchTokenExtractor(options.beam_size, ids.eot, options.patience)  # :135-143
         self.ranker = MaximumLikelihoodRanker(options.len_penalty)
-        self.prompt_ref = [DecodePrompt(options.prompt, ids)]
+        self.prompt_ref = [DecodePrompt(options.prompt, ids, options.sot_sequence_tail)]
+        self.languages = None  # per-audio language token (OpenAI decoding.py: tokens[:, sot_index + 1] = lang_tokens)
         self.filters = []
         if options.suppress_blank:  # :158-164
             self.filters.append(SuppressBlank(ids, self.prompt_ref))
@@ -312,7 +315,20 @@ class DecodeTask:
     def set_prompt(self, prompt):  # :206-218
         if prompt is not None and prompt.shape[0] == 0:
             prompt = None
-        self.prompt_ref[0] = DecodePrompt(prompt, self.ids)
+        self.prompt_ref[0] = DecodePrompt(prompt, self.ids, self.opt.sot_sequence_tail)
+
+    def detect_language(self, mel, first_language_id, n_languages=99):
+        """OpenAI whisper decoding.py detect_language (PARITY UNPINNED by the reference, which only declares
+        Task::LanguageId, tokenize.rs:135-139): logits of [sot] at position 0, every non-language token masked,
+        argmax + softmax."""
+        with torch.no_grad():
+            feats = self.model.encoder.forward(mel)
+            self.model.clear_cache()
+            x = torch.full((feats.shape[0], 1), self.ids.sot, dtype=torch.int64)
+            logits = self.model.decoder.forward_ext(x, feats, 0)[:, 0]
+            self.model.clear_cache()
+            lang = logits[:, first_language_id:first_language_id + n_languages].float()
+            return lang.argmax(dim=-1) + first_language_id, lang.softmax(dim=-1)
 
     def main_loop(self, audio_features, tokens):  # :220-282
         n_batch = tokens.shape[0]
@@ -359,6 +375,8 @@ class DecodeTask:
         n_audio = audio_features.shape[0]
         prompt = self.prompt_ref[0]
         repeated = prompt.initial_tokens.repeat(n_audio, 1)
+        if self.languages is not None:
+            repeated[:, prompt.sot_idx + 1] = torch.as_tensor(self.languages, dtype=torch.int64)[:n_audio]
         n_group = self.extractor.group_size()
         feats = audio_features.repeat_interleave(n_group, dim=0)  # :312
         repeated = repeated.repeat_interleave(n_group, dim=0)

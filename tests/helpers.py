@@ -48,3 +48,43 @@ def mel_windows(n, seed=1234):
     a = synth.make_audio(n, seed=seed)
     f = OA.mel_filter()
     return np.stack([OA.log_mel_spectrogram(torch.from_numpy(a[i]), f).numpy() for i in range(n)])
+
+
+@functools.lru_cache(maxsize=1)
+def synthetic_tokenizer_json(n_base=50256, seed=3):
+    """A full-size byte-level BPE tokenizer.json built without any corpus or download: the 256 byte symbols plus
+    pseudo-random merges up to n_base ids, then <|endoftext|> — the same id layout as the reference's gpt2.json
+    (specials start at 50257, timestamps at 50363), so model outputs decode to *some* text on machines that do not
+    have the reference's vocabulary (the GPU box)."""
+    import json
+    import random
+    direct = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    chars, nxt = {}, 256
+    for b in range(256):
+        if b in direct:
+            chars[b] = chr(b)
+        else:
+            chars[b] = chr(nxt)
+            nxt += 1
+    toks = [chars[b] for b in range(256)]
+    have = set(toks)
+    rng = random.Random(seed)
+    merges = []
+    while len(toks) < n_base:
+        l, r = toks[rng.randrange(len(toks))], toks[rng.randrange(len(toks))]
+        if len(l) + len(r) <= 12 and l + r not in have:
+            have.add(l + r)
+            toks.append(l + r)
+            merges.append(f"{l} {r}")
+    vocab = {t: i for i, t in enumerate(toks)}
+    vocab["<|endoftext|>"] = n_base
+    doc = {"version": "1.0", "truncation": None, "padding": None,
+           "added_tokens": [{"id": n_base, "content": "<|endoftext|>", "single_word": False, "lstrip": False, "rstrip": False,
+                             "normalized": True, "special": True}],
+           "normalizer": None,
+           "pre_tokenizer": {"type": "ByteLevel", "add_prefix_space": False, "trim_offsets": True, "use_regex": True},
+           "post_processor": {"type": "ByteLevel", "add_prefix_space": True, "trim_offsets": False, "use_regex": True},
+           "decoder": {"type": "ByteLevel", "add_prefix_space": True, "trim_offsets": True, "use_regex": True},
+           "model": {"type": "BPE", "dropout": None, "unk_token": None, "continuing_subword_prefix": "", "end_of_word_suffix": "",
+                     "fuse_unk": False, "vocab": vocab, "merges": merges}}
+    return json.dumps(doc, ensure_ascii=False).encode("utf-8")

@@ -46,3 +46,37 @@ def test_transcribe_chunked_equals_independent_windows(gpu):
     assert len(a.windows) == 4 and [w[0] for w in a.windows] == [0, 3000, 6000, 9000]
     _segments_equal(a.segments, b.segments)
     gt.close()
+
+
+def test_text_outputs_with_tokenizer(gpu):
+    """TranscribeOutput.text / segment text / DecodeOutput.text (transcribe.rs:200,227,236; decode/mod.rs:404) are the
+    attached tokenizer's decode of exactly the token slices the reference decodes; Text prompts are encoded by it."""
+    from helpers import synthetic_tokenizer_json
+    tok = gpu.Tokenizer.new_from_bytes(synthetic_tokenizer_json())
+    import dataclasses
+    assert dataclasses.replace(tok.ids, space=220) == TokenIds.english()  # same id layout; only the id of ' ' differs
+    audio = synth.make_audio(1, seed=77, n_samples=16000 * 50)[0]
+    gm = gpu_model(gpu, "nano")
+    dopt = gpu.DecodeOptions(sample_len=10)
+    plain = gpu.TranscribeTask(gm, gpu.TranscribeOptions(decode=dopt, prompt=gpu.TranscribePrompt.None_(True))).run(audio)
+    assert plain.text is None and all(s.text is None for s in plain.segments)
+    withtok = gpu.TranscribeTask(gm, gpu.TranscribeOptions(decode=dopt, prompt=gpu.TranscribePrompt.None_(True), tokenizer=tok)).run(audio)
+    np.testing.assert_array_equal(withtok.tokens, plain.tokens)
+    assert withtok.text == tok.decode(withtok.tokens)
+    assert len(withtok.segments) > 0
+    for s in withtok.segments:
+        assert isinstance(s.text, str)
+        if s.start_token > 0:  # consecutive-timestamp slice: tokens[start_token-1 : end_token] (transcribe.rs:186-200)
+            assert s.text == tok.decode(withtok.tokens[s.start_token - 1:s.end_token])
+    # TranscribePrompt::Text == Pretokenized(encode(text))
+    t1 = gpu.TranscribeTask(gm, gpu.TranscribeOptions(decode=dopt, prompt=gpu.TranscribePrompt.Text(" hello there"), tokenizer=tok)).run(audio)
+    t2 = gpu.TranscribeTask(gm, gpu.TranscribeOptions(decode=dopt, prompt=gpu.TranscribePrompt.Pretokenized(tok.encode(" hello there")))).run(audio)
+    np.testing.assert_array_equal(t1.tokens, t2.tokens)
+    assert t1.text.startswith(" hello there")
+    # DecodeTask with a tokenizer
+    from helpers import mel_windows
+    task = gpu.DecodeTask(gm, tok.ids, dopt)
+    task.set_tokenizer(tok)
+    out = task.run(mel_windows(1))[0]
+    assert out.text == tok.decode(out.tokens)
+    task.close()

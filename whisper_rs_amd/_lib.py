@@ -34,12 +34,14 @@ class DecodeOptionsC(C.Structure):
                 ("max_initial_timestamp", C.c_double), ("timestamps", C.c_int32), ("suppress_blank", C.c_int32),
                 ("suppress_non_speech", C.c_int32), ("suppress_tokens", C.POINTER(C.c_int32)), ("n_suppress_tokens", C.c_int32),
                 ("non_speech_tokens", C.POINTER(C.c_int32)), ("n_non_speech_tokens", C.c_int32),
-                ("position_offset_quirk", C.c_int32), ("max_audio", C.c_int32)]
+                ("position_offset_quirk", C.c_int32), ("max_audio", C.c_int32),
+                ("sot_sequence_tail", C.POINTER(C.c_int32)), ("n_sot_sequence_tail", C.c_int32)]
 
 
 class DecodeOutputC(C.Structure):
     _fields_ = [("tokens", C.POINTER(C.c_int64)), ("n_tokens", C.c_int32), ("avg_logprob", C.c_double),
-                ("no_speech_prob", C.c_double), ("sum_logprob", C.c_double), ("audio_features_device", C.c_void_p)]
+                ("no_speech_prob", C.c_double), ("sum_logprob", C.c_double), ("audio_features_device", C.c_void_p),
+                ("text", C.c_void_p)]
 
 
 class DecodeResultC(C.Structure):
@@ -53,13 +55,13 @@ class TranscribeOptionsC(C.Structure):
 
 class SegmentC(C.Structure):
     _fields_ = [("seek", C.c_int64), ("start_time", C.c_double), ("end_time", C.c_double), ("start_token", C.c_int64),
-                ("end_token", C.c_int64)]
+                ("end_token", C.c_int64), ("text", C.c_void_p)]
 
 
 class TranscribeOutputC(C.Structure):
     _fields_ = [("tokens", C.POINTER(C.c_int64)), ("n_tokens", C.c_int64), ("segments", C.POINTER(SegmentC)),
                 ("n_segments", C.c_int64), ("window_seek", C.POINTER(C.c_int64)), ("window_avg_logprob", C.POINTER(C.c_double)),
-                ("window_no_speech_prob", C.POINTER(C.c_double)), ("n_windows", C.c_int64)]
+                ("window_no_speech_prob", C.POINTER(C.c_double)), ("n_windows", C.c_int64), ("text", C.c_void_p)]
 
 
 class StageTimeC(C.Structure):
@@ -85,11 +87,28 @@ SYMBOLS = {
     "wrs_mel_filter": (C.c_int, [C.c_void_p]),
     "wrs_pad_or_trim": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "wrs_log_mel_spectrogram": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]),
+    "wrs_tokenizer_create_from_bytes": (C.c_int, [C.c_void_p, C.c_size_t, P(C.c_void_p)]),
+    "wrs_tokenizer_create_from_file": (C.c_int, [C.c_char_p, P(C.c_void_p)]),
+    "wrs_tokenizer_destroy": (None, [C.c_void_p]),
+    "wrs_tokenizer_token_ids": (C.c_int, [C.c_void_p, P(TokenIdsC)]),
+    "wrs_tokenizer_encode": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_int32, P(C.c_int32)]),
+    "wrs_tokenizer_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, P(C.c_void_p), P(C.c_size_t)]),
+    "wrs_string_free": (None, [C.c_void_p]),
+    "wrs_tokenizer_non_speech_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, P(C.c_int32)]),
+    "wrs_tokenizer_token_to_id": (C.c_int32, [C.c_void_p, C.c_char_p]),
+    "wrs_tokenizer_language_token": (C.c_int32, [C.c_void_p, C.c_char_p]),
+    "wrs_tokenizer_vocab_size": (C.c_int32, [C.c_void_p]),
+    "wrs_decode_task_set_tokenizer": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "wrs_transcribe_task_set_tokenizer": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "wrs_transcribe_task_set_prompt_text": (C.c_int, [C.c_void_p, C.c_char_p]),
     "wrs_decode_task_create": (C.c_int, [C.c_void_p, P(TokenIdsC), P(DecodeOptionsC), P(C.c_void_p)]),
     "wrs_decode_task_set_prompt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "wrs_decode_task_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, P(DecodeResultC)]),
     "wrs_decode_task_run_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, P(DecodeResultC)]),
     "wrs_decode_task_run_audio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, P(DecodeResultC)]),
+    "wrs_decode_task_run_encoded": (C.c_int, [C.c_void_p, C.c_int32, P(DecodeResultC)]),
+    "wrs_decode_task_detect_language": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "wrs_decode_task_set_languages": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "wrs_decode_task_trace": (C.c_int, [C.c_void_p, P(C.c_int32), P(C.c_int32), P(P(C.c_int32)), P(P(C.c_int32)), P(P(C.c_float))]),
     "wrs_decode_result_free": (None, [P(DecodeResultC)]),
     "wrs_decode_task_destroy": (None, [C.c_void_p]),

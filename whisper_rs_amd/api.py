@@ -63,6 +63,86 @@ class audio:
         return out[0] if single else out
 
 
+# ---------------------------------------------------------------------------- tokenizer
+def _take_text(ptr):
+    """UTF-8 text of a library-owned char* (or None)."""
+    return None if not ptr else C.string_at(ptr).decode("utf-8")
+
+
+class Tokenizer:
+    """reference `Tokenizer` (src/tokenize.rs:111-321): GPT-2 byte-level BPE + Whisper special ids, host-only."""
+
+    def __init__(self, handle):
+        self._lib = L.load()
+        self._h = handle
+        ids = L.TokenIdsC()
+        L.check(self._lib.wrs_tokenizer_token_ids(self._h, C.byref(ids)))
+        self.ids = TokenIds(**{k: getattr(ids, k) for k, _ in L.TokenIdsC._fields_})
+
+    @staticmethod
+    def new_from_bytes(data: bytes) -> "Tokenizer":
+        h = C.c_void_p()
+        buf = C.create_string_buffer(data, len(data))
+        L.check(L.load().wrs_tokenizer_create_from_bytes(buf, len(data), C.byref(h)))
+        return Tokenizer(h)
+
+    @staticmethod
+    def new_from_file(path: str) -> "Tokenizer":
+        h = C.c_void_p()
+        L.check(L.load().wrs_tokenizer_create_from_file(str(path).encode(), C.byref(h)))
+        return Tokenizer(h)
+
+    def encode(self, text: str) -> List[int]:
+        raw = text.encode("utf-8")
+        cap = max(16, len(raw) + 8)
+        out = (C.c_int32 * cap)()
+        n = C.c_int32()
+        L.check(self._lib.wrs_tokenizer_encode(self._h, raw, len(raw), out, cap, C.byref(n)))
+        assert n.value <= cap
+        return list(out[:n.value])
+
+    def decode(self, tokens) -> str:
+        t = np.ascontiguousarray(tokens, dtype=np.int64)
+        p, n = C.c_void_p(), C.c_size_t()
+        L.check(self._lib.wrs_tokenizer_decode(self._h, _ptr(t) if t.size else None, t.size, C.byref(p), C.byref(n)))
+        try:
+            return C.string_at(p.value, n.value).decode("utf-8")
+        finally:
+            self._lib.wrs_string_free(p)
+
+    def non_speech_tokens(self) -> List[int]:
+        out = (C.c_int32 * 256)()
+        n = C.c_int32()
+        L.check(self._lib.wrs_tokenizer_non_speech_tokens(self._h, out, 256, C.byref(n)))
+        return list(out[:n.value])
+
+    def token_to_id(self, token: str) -> Optional[int]:
+        i = self._lib.wrs_tokenizer_token_to_id(self._h, token.encode("utf-8"))
+        return None if i < 0 else i
+
+    def language_token(self, code: str) -> Optional[int]:
+        i = self._lib.wrs_tokenizer_language_token(self._h, code.encode("utf-8"))
+        return None if i < 0 else i
+
+    def vocab_size(self) -> int:
+        return self._lib.wrs_tokenizer_vocab_size(self._h)
+
+    def sequence_sot(self) -> List[int]:
+        """`Tokenizer::sequence_sot()` (tokenize.rs:209-213)."""
+        return [self.ids.sot]
+
+    def close(self):
+        if self._h:
+            self._lib.wrs_tokenizer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------------- model
 class Whisper:
     """reference `Whisper` (src/model.rs:538-604).  Weights are given as a dict of VarStore paths
@@ -174,6 +254,7 @@ class DecodeOptions:
     position_offset_quirk: bool = True   # keep the reference's decoder offset = loop index
     max_audio: int = 1                   # windows per run()
     non_speech_tokens: Sequence[int] = NON_SPEECH_TOKENS
+    sot_sequence_tail: Optional[Sequence[int]] = None  # tokens after <|startoftranscript|>: [lang, task] for multilingual models
 
 
 @dataclass
@@ -184,6 +265,7 @@ class DecodeOutput:
     no_speech_prob: float
     sum_logprob: float
     audio_features_device: int  # device pointer to [1500, D] fp32
+    text: Optional[str] = None  # filled when the task has a tokenizer (decode/mod.rs:404)
 
 
 def _fill_decode_options(o: DecodeOptions, keep: list) -> L.DecodeOptionsC:
@@ -208,6 +290,10 @@ def _fill_decode_options(o: DecodeOptions, keep: list) -> L.DecodeOptionsC:
     c.n_non_speech_tokens = ns.size
     c.position_offset_quirk = o.position_offset_quirk
     c.max_audio = o.max_audio
+    tail = np.asarray(list(o.sot_sequence_tail or []), dtype=np.int32)
+    keep.append(tail)
+    c.sot_sequence_tail = tail.ctypes.data_as(C.POINTER(C.c_int32)) if tail.size else None
+    c.n_sot_sequence_tail = tail.size
     return c
 
 
@@ -233,12 +319,17 @@ class DecodeTask:
         p = np.ascontiguousarray(prompt if prompt is not None else [], dtype=np.int64)
         L.check(self._lib.wrs_decode_task_set_prompt(self._h, _ptr(p) if p.size else None, p.size))
 
+    def set_tokenizer(self, tokenizer: Optional["Tokenizer"]):
+        """the reference passes Rc<Tokenizer> to DecodeTask::new (decode/mod.rs:122-126); with it outputs carry text."""
+        self._tokenizer = tokenizer
+        L.check(self._lib.wrs_decode_task_set_tokenizer(self._h, tokenizer._h if tokenizer else None))
+
     def _collect(self, res):
         outs = []
         for i in range(res.n_outputs):
             o = res.outputs[i]
             toks = np.ctypeslib.as_array(o.tokens, shape=(o.n_tokens,)).copy() if o.n_tokens > 0 else np.zeros(0, np.int64)
-            outs.append(DecodeOutput(toks, o.avg_logprob, o.no_speech_prob, o.sum_logprob, o.audio_features_device or 0))
+            outs.append(DecodeOutput(toks, o.avg_logprob, o.no_speech_prob, o.sum_logprob, o.audio_features_device or 0, _take_text(o.text)))
         self.n_steps = res.n_steps
         self._lib.wrs_decode_result_free(C.byref(res))
         return outs
@@ -265,6 +356,29 @@ class DecodeTask:
         res = L.DecodeResultC()
         L.check(self._lib.wrs_decode_task_run_audio(self._h, _ptr(a), a.shape[0], L.WRS_MEM_HOST, C.byref(res)))
         return self._collect(res)
+
+    def run_encoded(self, n_audio: int) -> List[DecodeOutput]:
+        """decode the windows whose encoder output is still resident (after detect_language / a previous run)."""
+        res = L.DecodeResultC()
+        L.check(self._lib.wrs_decode_task_run_encoded(self._h, n_audio, C.byref(res)))
+        return self._collect(res)
+
+    def detect_language(self, mel: np.ndarray, first_language_id: int, n_languages: int = 99):
+        """OpenAI whisper `detect_language` (the reference only declares Task::LanguageId): returns
+        (language token id per window [n], probabilities [n, n_languages])."""
+        mel = _f32(mel)
+        if mel.ndim == 2:
+            mel = mel[None]
+        n = mel.shape[0]
+        ids = np.empty(n, np.int32)
+        probs = np.empty((n, n_languages), np.float32)
+        L.check(self._lib.wrs_decode_task_detect_language(self._h, _ptr(mel), n, L.WRS_MEM_HOST, first_language_id, n_languages,
+                                                          _ptr(ids), _ptr(probs)))
+        return ids, probs
+
+    def set_languages(self, language_ids):
+        a = np.ascontiguousarray(language_ids if language_ids is not None else [], dtype=np.int32)
+        L.check(self._lib.wrs_decode_task_set_languages(self._h, _ptr(a) if a.size else None, a.size))
 
     def run_audio_device(self, dev_ptr: int, n_audio: int) -> List[DecodeOutput]:
         """audio windows already resident in HBM ([n_audio, 480000] f32)."""
@@ -356,10 +470,15 @@ class TranscribePrompt:
     """reference enum `TranscribePrompt` (transcribe.rs:25-29); Text needs the BPE tokenizer."""
     pretokenized: Optional[List[int]] = None
     condition_on_prev_text: bool = True
+    text: Optional[str] = None
 
     @staticmethod
     def Pretokenized(tokens):
         return TranscribePrompt(list(tokens), True)
+
+    @staticmethod
+    def Text(text):
+        return TranscribePrompt(None, True, text)
 
     @staticmethod
     def None_(condition_on_prev_text=True):
@@ -372,6 +491,7 @@ class TranscribeOptions:
     decode: DecodeOptions = field(default_factory=DecodeOptions)
     prompt: TranscribePrompt = field(default_factory=TranscribePrompt)
     tokenizer_ids: TokenIds = field(default_factory=TokenIds.english)
+    tokenizer: Optional[Tokenizer] = None  # reference `TranscribeOptions.tokenizer` (transcribe.rs:49); gives text outputs
 
 
 @dataclass
@@ -381,6 +501,7 @@ class TranscribeOutputSegment:
     end_time: float
     start_token: int
     end_token: int
+    text: Optional[str] = None
 
 
 @dataclass
@@ -388,6 +509,7 @@ class TranscribeOutput:
     tokens: np.ndarray
     segments: List[TranscribeOutputSegment]
     windows: list  # (seek, avg_logprob, no_speech_prob)
+    text: Optional[str] = None
 
 
 class TranscribeTask:
@@ -406,17 +528,22 @@ class TranscribeTask:
             c.prompt_tokens = arr.ctypes.data_as(C.POINTER(C.c_int64))
             c.n_prompt_tokens = arr.size
         c.condition_on_prev_text = p.condition_on_prev_text
-        ids = _ids_c(options.tokenizer_ids)
+        ids = _ids_c(options.tokenizer.ids if options.tokenizer is not None else options.tokenizer_ids)
         self._h = C.c_void_p()
         L.check(self._lib.wrs_transcribe_task_create(model._h, C.byref(ids), C.byref(c), C.byref(self._h)))
+        if options.tokenizer is not None:
+            L.check(self._lib.wrs_transcribe_task_set_tokenizer(self._h, options.tokenizer._h))
+        if p.text is not None:
+            L.check(self._lib.wrs_transcribe_task_set_prompt_text(self._h, p.text.encode("utf-8")))
 
     def _collect(self, out):
         toks = np.ctypeslib.as_array(out.tokens, shape=(out.n_tokens,)).copy() if out.n_tokens else np.zeros(0, np.int64)
-        segs = [TranscribeOutputSegment(s.seek, s.start_time, s.end_time, s.start_token, s.end_token)
+        segs = [TranscribeOutputSegment(s.seek, s.start_time, s.end_time, s.start_token, s.end_token, _take_text(s.text))
                 for s in (out.segments[i] for i in range(out.n_segments))]
         wins = [(out.window_seek[i], out.window_avg_logprob[i], out.window_no_speech_prob[i]) for i in range(out.n_windows)]
+        text = _take_text(out.text)
         self._lib.wrs_transcribe_output_free(C.byref(out))
-        return TranscribeOutput(toks, segs, wins)
+        return TranscribeOutput(toks, segs, wins, text)
 
     def run(self, audio_: np.ndarray) -> TranscribeOutput:
         a = _f32(audio_)

@@ -47,6 +47,7 @@ MODEL_DIMS = {
     "large-v2": _dims(51865, 1280, 20, 32),
     # test-only shapes (same architecture, fewer/smaller layers so the CPU oracle is quick)
     "micro": _dims(51864, 128, 2, 2),
+    "micro.ml": _dims(51865, 128, 2, 2),  # multilingual vocabulary layout
     "nano": _dims(51864, 64, 1, 1),
 }
 

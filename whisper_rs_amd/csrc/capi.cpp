@@ -3,10 +3,13 @@
 #include "transcribe.h"
 #include <map>
 #include <mutex>
+#include <fstream>
+#include <sstream>
 
 struct wrs_model { wrs::Model m; };
 struct wrs_decode_task { wrs::DecodeTask t; };
 struct wrs_transcribe_task { wrs::TranscribeTask t; };
+struct wrs_tokenizer { wrs::Tokenizer t; };
 
 namespace wrs {
 const std::string& last_error();
@@ -230,6 +233,7 @@ int wrs_decode_task_run_features(wrs_decode_task* t, const float* feats, int32_t
         const size_t n = (size_t)n_audio * m.T * m.D;
         HIP_CHECK(hipMemcpyAsync(m.enc_ws.xa32.p, feats, n * 4, mem_kind == WRS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m.stream));
         launch_f32_to_f16(m.enc_ws.xa32.as<float>(), m.enc_ws.xa16.as<half_t>(), (int64_t)n, m.stream);
+        m.enc_ws.n_encoded = n_audio;
         t->t.run_encoded(n_audio, result);
     });
 }
@@ -254,6 +258,29 @@ int wrs_decode_task_run_audio(wrs_decode_task* t, const float* audio, int32_t n_
         m.load_mel(d.mel_dev.as<float>(), n_audio, WRS_MEM_DEVICE, WRS_N_FRAMES, 0);
         d.run_loaded(n_audio, result);
     });
+}
+int wrs_decode_task_run_encoded(wrs_decode_task* t, int32_t n_audio, wrs_decode_result* result) {
+    return guarded([&] {
+        WRS_REQUIRE(t && result, "wrs_decode_task_run_encoded: null argument");
+        WRS_REQUIRE(n_audio >= 1 && n_audio <= t->t.m->enc_ws.n_encoded, "wrs_decode_task_run_encoded: %d windows requested, %d encoded", n_audio, t->t.m->enc_ws.n_encoded);
+        t->t.m->use();
+        t->t.run_encoded(n_audio, result);
+    });
+}
+int wrs_decode_task_detect_language(wrs_decode_task* t, const float* mel, int32_t n_audio, int mem_kind, int32_t first_language_id,
+                                    int32_t n_languages, int32_t* out_language_ids, float* out_probs) {
+    return guarded([&] {
+        WRS_REQUIRE(t && mel && out_language_ids, "wrs_decode_task_detect_language: null argument");
+        WRS_REQUIRE(n_audio >= 1 && n_audio <= t->t.max_audio, "wrs_decode_task_detect_language: %d windows exceed capacity %d", n_audio, t->t.max_audio);
+        Model& m = *t->t.m;
+        m.use();
+        m.load_mel(mel, n_audio, mem_kind, WRS_N_FRAMES, 0);
+        m.encoder_from_mel_t(n_audio);
+        t->t.detect_language(n_audio, first_language_id, n_languages, out_language_ids, out_probs);
+    });
+}
+int wrs_decode_task_set_languages(wrs_decode_task* t, const int32_t* language_ids, int32_t n) {
+    return guarded([&] { WRS_REQUIRE(t, "null task"); t->t.set_languages(language_ids, n); });
 }
 int wrs_decode_task_trace(wrs_decode_task* t, int32_t* n_steps, int32_t* n_rows, const int32_t** tokens, const int32_t** sources, const float** slp) {
     return guarded([&] {
@@ -306,6 +333,60 @@ int wrs_filter_topk(wrs_decode_task* t, const float* logits, const int64_t* toke
     });
 }
 
+int wrs_decode_task_set_tokenizer(wrs_decode_task* t, const wrs_tokenizer* tok) {
+    return guarded([&] { WRS_REQUIRE(t, "null task"); t->t.tokenizer = tok ? &tok->t : nullptr; });
+}
+
+// ------------------------------------------------------------------ tokenizer (host only)
+int wrs_tokenizer_create_from_bytes(const void* bytes, size_t n_bytes, wrs_tokenizer** out) {
+    return guarded([&] {
+        WRS_REQUIRE(bytes && out, "wrs_tokenizer_create_from_bytes: null argument");
+        std::unique_ptr<wrs_tokenizer> h(new wrs_tokenizer());
+        h->t.load_json((const char*)bytes, n_bytes, false);
+        *out = h.release();
+    });
+}
+int wrs_tokenizer_create_from_file(const char* path, wrs_tokenizer** out) {
+    return guarded([&] {
+        WRS_REQUIRE(path && out, "wrs_tokenizer_create_from_file: null argument");
+        std::ifstream f(path, std::ios::binary);
+        WRS_REQUIRE(f.good(), "failed to read tokenizer file %s", path);
+        std::stringstream ss;
+        ss << f.rdbuf();
+        const std::string bytes = ss.str();
+        std::unique_ptr<wrs_tokenizer> h(new wrs_tokenizer());
+        h->t.load_json(bytes.data(), bytes.size(), false);
+        *out = h.release();
+    });
+}
+void wrs_tokenizer_destroy(wrs_tokenizer* t) { delete t; }
+int wrs_tokenizer_token_ids(const wrs_tokenizer* t, wrs_token_ids* out) {
+    return guarded([&] { WRS_REQUIRE(t && out, "null argument"); *out = t->t.ids; });
+}
+static void copy_ids(const std::vector<int32_t>& v, int32_t* out, int32_t cap, int32_t* n) {
+    WRS_REQUIRE(n && cap >= 0 && (out || cap == 0), "bad output buffer");
+    *n = (int32_t)v.size();
+    for (int32_t i = 0; i < cap && i < *n; ++i) out[i] = v[i];
+}
+int wrs_tokenizer_encode(const wrs_tokenizer* t, const char* utf8, size_t n_bytes, int32_t* out, int32_t cap, int32_t* n) {
+    return guarded([&] { WRS_REQUIRE(t && (utf8 || n_bytes == 0), "null argument"); copy_ids(t->t.encode(std::string(utf8 ? utf8 : "", n_bytes)), out, cap, n); });
+}
+int wrs_tokenizer_decode(const wrs_tokenizer* t, const int64_t* ids, int64_t n, char** out_text, size_t* out_len) {
+    return guarded([&] {
+        WRS_REQUIRE(t && out_text && n >= 0 && (ids || n == 0), "null argument");
+        const std::string s = t->t.decode(ids, n);
+        *out_text = dup_cstr(s);
+        if (out_len) *out_len = s.size();
+    });
+}
+void wrs_string_free(char* s) { free(s); }
+int wrs_tokenizer_non_speech_tokens(const wrs_tokenizer* t, int32_t* out, int32_t cap, int32_t* n) {
+    return guarded([&] { WRS_REQUIRE(t, "null argument"); copy_ids(t->t.non_speech_tokens(), out, cap, n); });
+}
+int32_t wrs_tokenizer_token_to_id(const wrs_tokenizer* t, const char* token) { return (t && token) ? t->t.token_to_id(token) : -1; }
+int32_t wrs_tokenizer_language_token(const wrs_tokenizer* t, const char* code) { return (t && code) ? t->t.language_token(code) : -1; }
+int32_t wrs_tokenizer_vocab_size(const wrs_tokenizer* t) { return t ? (int32_t)t->t.id_to_tok.size() : 0; }
+
 // ------------------------------------------------------------------ transcribe
 int wrs_transcribe_task_create(wrs_model* m, const wrs_token_ids* ids, const wrs_transcribe_options* opt, wrs_transcribe_task** out) {
     return guarded([&] {
@@ -315,6 +396,12 @@ int wrs_transcribe_task_create(wrs_model* m, const wrs_token_ids* ids, const wrs
         *out = h.release();
     });
 }
+int wrs_transcribe_task_set_tokenizer(wrs_transcribe_task* t, const wrs_tokenizer* tok) {
+    return guarded([&] { WRS_REQUIRE(t, "null task"); t->t.set_tokenizer(tok ? &tok->t : nullptr); });
+}
+int wrs_transcribe_task_set_prompt_text(wrs_transcribe_task* t, const char* utf8) {
+    return guarded([&] { WRS_REQUIRE(t, "null task"); t->t.set_prompt_text(utf8); });
+}
 int wrs_transcribe_task_run(wrs_transcribe_task* t, const float* audio, int64_t n, wrs_transcribe_output* out) {
     return guarded([&] { WRS_REQUIRE(t, "null task"); t->t.run(audio, n, out); });
 }
@@ -323,6 +410,9 @@ int wrs_transcribe_task_run_chunked(wrs_transcribe_task* t, const float* audio, 
 }
 void wrs_transcribe_output_free(wrs_transcribe_output* o) {
     if (!o) return;
+    if (o->segments)
+        for (int64_t i = 0; i < o->n_segments; ++i) free(o->segments[i].text);
+    free(o->text);
     free(o->tokens); free(o->segments); free(o->window_seek); free(o->window_avg_logprob); free(o->window_no_speech_prob);
     memset(o, 0, sizeof(*o));
 }

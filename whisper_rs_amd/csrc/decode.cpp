@@ -64,6 +64,12 @@ void DecodeTask::configure(Model* model, const wrs_token_ids& tid, const wrs_dec
     suppress_dev.alloc(std::max<size_t>(suppress_ids.size(), 1) * 4);
     if (!suppress_ids.empty())
         HIP_CHECK(hipMemcpy(suppress_dev.p, suppress_ids.data(), suppress_ids.size() * 4, hipMemcpyHostToDevice));
+    sot_tail.clear();
+    audio_lang.clear();
+    for (int i = 0; i < o.n_sot_sequence_tail; ++i) {
+        WRS_REQUIRE(o.sot_sequence_tail && o.sot_sequence_tail[i] >= 0 && o.sot_sequence_tail[i] < V, "DecodeTask: sot sequence token out of range");
+        sot_tail.push_back(o.sot_sequence_tail[i]);
+    }
     m->init_state(st, max_audio, group);
     set_prompt(nullptr, 0);
     const char* env = getenv("WRS_NO_GRAPH");
@@ -79,11 +85,43 @@ void DecodeTask::set_prompt(const int64_t* p, int n) {  // decode/mod.rs:46-92,2
             initial_tokens.push_back(p[i]);
         }
     }
-    initial_tokens.push_back(ids.sot);  // sequence_sot() == [sot] (tokenize.rs:201-205)
+    initial_tokens.push_back(ids.sot);  // sequence_sot() == [sot] (tokenize.rs:209-213)
+    for (int64_t t : sot_tail) initial_tokens.push_back(t);  // multilingual: [sot, lang, task]
     sample_begin = (int)initial_tokens.size();
     sot_idx = 0;
     for (size_t i = 0; i < initial_tokens.size(); ++i)
         if (initial_tokens[i] == ids.sot) { sot_idx = (int)i; break; }
+}
+
+void DecodeTask::set_languages(const int32_t* lang, int n) {
+    if (n <= 0 || !lang) { audio_lang.clear(); return; }
+    WRS_REQUIRE(!sot_tail.empty(), "set_languages: the task has no language slot (n_sot_sequence_tail == 0)");
+    WRS_REQUIRE(n <= max_audio, "set_languages: %d languages exceed the task capacity %d", n, max_audio);
+    for (int i = 0; i < n; ++i) WRS_REQUIRE(lang[i] >= 0 && lang[i] < m->V, "set_languages: token %d out of range", lang[i]);
+    audio_lang.assign(lang, lang + n);
+}
+
+// OpenAI whisper decoding.py detect_language: logits of the decoder on [sot] at position 0, restricted to the
+// language tokens; argmax + softmax.  The encoder output of the windows is in m->enc_ws.xa16.
+void DecodeTask::detect_language(int n_audio, int first_id, int n_lang, int32_t* out_ids, float* out_probs) {
+    WRS_REQUIRE(n_audio >= 1 && n_audio <= max_audio, "detect_language: %d windows exceed the task capacity %d", n_audio, max_audio);
+    WRS_REQUIRE(out_ids && first_id >= 0 && n_lang >= 1 && first_id + n_lang <= m->V, "detect_language: bad language id range");
+    m->use();
+    hipStream_t s = m->stream;
+    m->load_cross_kv(st, m->enc_ws.xa16.as<half_t>(), n_audio);
+    launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m->n_ctx, m->n_ctx, st.r_cap, group, s);
+    StepParams* sp = st.sp_h();
+    sp->cache_pos = 0; sp->pos_idx = 0; sp->parity = 0; sp->first_step = 1; sp->want_no_speech = 0; sp->n_rows = n_audio;
+    for (int a = 0; a < n_audio; ++a) { st.tokens_h()[a] = ids.sot; st.src_h()[a] = a; st.tsmode_h()[a] = 0; }
+    upload_step(n_audio);
+    m->decoder_step(st, n_audio, group, 1, false, true);
+    DevBuf d_ids, d_probs;
+    d_ids.alloc((size_t)n_audio * 4);
+    d_probs.alloc((size_t)n_audio * n_lang * 4);
+    launch_lang_detect(st.logits.as<float>(), n_audio, st.logits_ld, first_id, n_lang, d_ids.as<int>(), d_probs.as<float>(), s);
+    HIP_CHECK(hipMemcpyAsync(out_ids, d_ids.p, (size_t)n_audio * 4, hipMemcpyDeviceToHost, s));
+    if (out_probs) HIP_CHECK(hipMemcpyAsync(out_probs, d_probs.p, (size_t)n_audio * n_lang * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
 }
 
 FilterCfg DecodeTask::filter_cfg() const {
@@ -280,6 +318,10 @@ void DecodeTask::run_encoded(int n_audio, wrs_decode_result* out) {
 
     // host state (decode/mod.rs:297-325)
     rows.assign(R, initial_tokens);
+    if (!audio_lang.empty()) {
+        WRS_REQUIRE((int)audio_lang.size() >= n_audio, "run: %d windows but only %d languages set", n_audio, (int)audio_lang.size());
+        for (int r = 0; r < R; ++r) rows[r][sot_idx + 1] = audio_lang[r / G];
+    }
     sum_logprobs.assign(R, 0.f);
     sources.assign(R, 0);
     finished.assign(n_audio, {});
@@ -297,7 +339,7 @@ void DecodeTask::run_encoded(int n_audio, wrs_decode_result* out) {
         StepParams* sp = st.sp_h();
         sp->cache_pos = p; sp->pos_idx = p; sp->parity = 0; sp->first_step = 1;
         sp->want_no_speech = (p == sot_idx) ? 1 : 0; sp->n_rows = n_audio;
-        for (int a = 0; a < n_audio; ++a) { st.tokens_h()[a] = (int)initial_tokens[p]; st.src_h()[a] = a; st.tsmode_h()[a] = 0; }
+        for (int a = 0; a < n_audio; ++a) { st.tokens_h()[a] = (int)initial_token(a, p); st.src_h()[a] = a; st.tsmode_h()[a] = 0; }
         upload_step(n_audio);
         const bool last = (p == S - 1);
         const bool want_logits = last || p == sot_idx;
@@ -482,12 +524,20 @@ void DecodeTask::finalize(int n_audio, wrs_decode_result* out) {
         o.avg_logprob = cands[i][best].score / ((double)o.n_tokens + 1.0);
         o.no_speech_prob = no_speech[i];
         o.audio_features_device = m->enc_ws.xa32.as<float>() + (size_t)i * m->T * m->D;
+        o.text = tokenizer ? dup_cstr(tokenizer->decode(o.tokens, o.n_tokens)) : nullptr;  // decode/mod.rs:404
     }
+}
+
+char* dup_cstr(const std::string& s) {
+    char* p = (char*)malloc(s.size() + 1);
+    memcpy(p, s.data(), s.size());
+    p[s.size()] = 0;
+    return p;
 }
 
 void free_decode_result(wrs_decode_result* r) {
     if (!r || !r->outputs) return;
-    for (int i = 0; i < r->n_outputs; ++i) free(r->outputs[i].tokens);
+    for (int i = 0; i < r->n_outputs; ++i) { free(r->outputs[i].tokens); free(r->outputs[i].text); }
     free(r->outputs);
     r->outputs = nullptr;
     r->n_outputs = 0;

@@ -1,6 +1,7 @@
 // DecodeTask: one <=30-s window batch: encoder -> sampling loop -> rank (reference src/decode/mod.rs).
 #pragma once
 #include "model.h"
+#include "tokenizer.h"
 
 namespace wrs {
 
@@ -12,6 +13,7 @@ struct FinishedSeq {
 struct DecodeTask {
     Model* m = nullptr;
     wrs_token_ids ids{};
+    const Tokenizer* tokenizer = nullptr;  // optional: fills DecodeOutput.text (decode/mod.rs:404)
     // options (reference DecodeOptions, decode/mod.rs:95-106)
     int sample_len = 0;
     int mode = WRS_EXTRACT_BEAM_SEARCH;
@@ -29,6 +31,12 @@ struct DecodeTask {
     // prompt (reference DecodePrompt, decode/mod.rs:46-92)
     std::vector<int64_t> initial_tokens;
     int sample_begin = 1, sot_idx = 0;
+    std::vector<int64_t> sot_tail;    // sequence_sot() after the sot token (empty = the reference)
+    std::vector<int64_t> audio_lang;  // per-window replacement of sot_tail[0] (language token), or empty
+    std::vector<int64_t> last_prompt; // the prompt given to set_prompt (kept so the sot sequence can be rebuilt)
+    int64_t initial_token(int audio, int p) const {
+        return (!audio_lang.empty() && p == sot_idx + 1 && audio < (int)audio_lang.size()) ? audio_lang[audio] : initial_tokens[p];
+    }
 
     DecState st;
     MelWorkspace mel_ws;
@@ -66,6 +74,9 @@ struct DecodeTask {
     void run_encoded(int n_audio, wrs_decode_result* out);
     // test hook: follow externally given beam decisions (tokens/sources per step) and return the device's raw
     // per-step top-k candidates; the window batch must already be in m->enc_ws.mel_t
+    // language identification on the encoder output in m->enc_ws.xa16 (OpenAI detect_language)
+    void detect_language(int n_audio, int first_id, int n_lang, int32_t* out_ids, float* out_probs);
+    void set_languages(const int32_t* lang, int n);
     void run_forced(int n_audio, int n_steps, const int32_t* ftok, const int32_t* fsrc, float* out_lp, int32_t* out_id,
                     double* out_no_speech);
 
@@ -78,5 +89,6 @@ struct DecodeTask {
 };
 
 void free_decode_result(wrs_decode_result* r);
+char* dup_cstr(const std::string& s);  // malloc-ed copy (released by the *_free entry points)
 
 }  // namespace wrs

@@ -167,4 +167,7 @@ struct FilterCfg {
 void launch_filter_topk(const float* logits, int n_rows, const FilterCfg& cfg, const StepParams* sp, const int* ts_mode,
                         int k, float* out_lp, int* out_id, float* no_speech, float* out_filtered, hipStream_t s);
 
+// softmax over logits[r, first_id : first_id + n_lang] -> out_probs [n_rows, n_lang] (optional), out_id[r] = argmax id
+void launch_lang_detect(const float* logits, int n_rows, int ld, int first_id, int n_lang, int* out_id, float* out_probs, hipStream_t s);
+
 }  // namespace wrs

@@ -226,6 +226,33 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
     }
 }
 
+// Language detection (OpenAI whisper `detect_language`; the reference declares Task::LanguageId, tokenize.rs:135-139,
+// but does not implement it — BASELINE config 4): softmax restricted to the language tokens of the logits at the
+// <|startoftranscript|> position.  One wave per audio; the <= 128 language logits sit two per lane.
+__global__ __launch_bounds__(64) void lang_detect_kernel(const float* __restrict__ logits, int ld, int first, int n,
+                                                          int* __restrict__ out_id, float* __restrict__ out_probs) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const float* x = logits + (int64_t)row * ld + first;
+    const float a = lane < n ? x[lane] : -INFINITY, b = lane + 64 < n ? x[lane + 64] : -INFINITY;
+    const float mx = wave_max(fmaxf(a, b));
+    const float ea = lane < n ? __expf(a - mx) : 0.f, eb = lane + 64 < n ? __expf(b - mx) : 0.f;
+    const float sum = wave_add(ea + eb);
+    if (out_probs) {
+        if (lane < n) out_probs[(int64_t)row * n + lane] = ea / sum;
+        if (lane + 64 < n) out_probs[(int64_t)row * n + lane + 64] = eb / sum;
+    }
+    // argmax, lowest index on ties (torch.argmax)
+    int idx = (a == mx && lane < n) ? lane : ((b == mx && lane + 64 < n) ? lane + 64 : 0x7fffffff);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) idx = min(idx, __shfl_xor(idx, o));
+    if (lane == 0) out_id[row] = first + idx;
+}
+
+void launch_lang_detect(const float* logits, int n_rows, int ld, int first_id, int n_lang, int* out_id, float* out_probs, hipStream_t s) {
+    WRS_REQUIRE(n_lang >= 1 && n_lang <= 128 && first_id >= 0, "lang_detect: %d languages not in 1..128", n_lang);
+    lang_detect_kernel<<<n_rows, 64, 0, s>>>(logits, ld, first_id, n_lang, out_id, out_probs);
+}
+
 void launch_filter_topk(const float* logits, int n_rows, const FilterCfg& cfg, const StepParams* sp, const int* ts_mode,
                         int k, float* out_lp, int* out_id, float* no_speech, float* out_filtered, hipStream_t s) {
     WRS_REQUIRE(k >= 1 && k <= TOPK_MAX, "filter_topk: k=%d not in 1..%d", k, TOPK_MAX);

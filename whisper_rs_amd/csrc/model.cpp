@@ -318,6 +318,7 @@ void Model::encoder_from_mel_t(int n) {
     WRS_REQUIRE(finalized, "model not finalized");
     WRS_REQUIRE(n >= 1 && n <= enc_ws.cap, "encoder: bad window count %d", n);
     EncoderWorkspace& w = enc_ws;
+    w.n_encoded = n;
     const int64_t M = (int64_t)n * T;
     const float scale = std::pow((float)(D / H), -0.25f);
     const double dM = (double)M, dD = (double)D;

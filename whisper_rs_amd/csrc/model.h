@@ -29,6 +29,7 @@ struct BlockW {
 
 struct EncoderWorkspace {
     int cap = 0;  // windows
+    int n_encoded = 0;  // windows whose encoder output currently sits in xa16/xa32
     DevBuf mel_t, c1, x, xn, qkv, kp, vp, att, h, xa16, xa32;
 };
 

@@ -22,7 +22,17 @@ void TranscribeTask::configure(Model* model, const wrs_token_ids& ids, const wrs
     condition = (o.prompt_tokens != nullptr) ? true : (o.condition_on_prev_text != 0);
 }
 
+void TranscribeTask::set_prompt_text(const char* utf8) {
+    WRS_REQUIRE(dt.tokenizer, "transcribe: a Text prompt needs a tokenizer (wrs_transcribe_task_set_tokenizer)");
+    WRS_REQUIRE(utf8, "transcribe: null prompt text");
+    const std::vector<int32_t> t = dt.tokenizer->encode(utf8);
+    prompt.assign(t.begin(), t.end());
+    has_prompt = true;
+    condition = true;  // transcribe.rs:142-147
+}
+
 struct OutBuilder {
+    const Tokenizer* tok = nullptr;
     std::vector<int64_t> tokens;
     std::vector<wrs_segment> segments;
     std::vector<int64_t> wseek;
@@ -42,6 +52,7 @@ struct OutBuilder {
         memcpy(out->window_seek, wseek.data(), wseek.size() * sizeof(int64_t));
         memcpy(out->window_avg_logprob, wavg.data(), wavg.size() * sizeof(double));
         memcpy(out->window_no_speech_prob, wns.data(), wns.size() * sizeof(double));
+        out->text = tok ? dup_cstr(tok->decode(tokens.data(), (int64_t)tokens.size())) : nullptr;  // transcribe.rs:236
     }
 };
 
@@ -59,7 +70,8 @@ static int64_t absorb_window(OutBuilder& ob, const int64_t* seg, int n, int64_t 
         for (int cur : consecutive) {
             const int64_t start_pos = seg[last_slice] - tsb, end_pos = seg[cur - 1] - tsb;
             ob.segments.push_back({seek, ts_offset + (double)start_pos * time_precision, ts_offset + (double)end_pos * time_precision,
-                                   token_offset + last_slice + 1, token_offset + cur});
+                                   token_offset + last_slice + 1, token_offset + cur,
+                                   ob.tok ? dup_cstr(ob.tok->decode(seg + last_slice, cur - last_slice)) : nullptr});  // :200
             last_slice = cur;
         }
         const int64_t last_ts_pos = seg[last_slice - 1] - tsb;
@@ -78,7 +90,8 @@ static int64_t absorb_window(OutBuilder& ob, const int64_t* seg, int n, int64_t 
     for (int q = 0; q < n; ++q)
         if (seg[q] >= tsb) last_ts = seg[q];
     if (last_ts >= 0 && last_ts != tsb) duration = (double)(last_ts - tsb) * time_precision;
-    ob.segments.push_back({seek, ts_offset, ts_offset + duration, 0, (int64_t)n});
+    ob.segments.push_back({seek, ts_offset, ts_offset + duration, 0, (int64_t)n,
+                           ob.tok ? dup_cstr(ob.tok->decode(seg, n)) : nullptr});  // :227 (result.text)
     ob.tokens.insert(ob.tokens.end(), seg, seg + n);
     return WRS_N_FRAMES;
 }
@@ -100,6 +113,7 @@ void TranscribeTask::run(const float* audio, int64_t n, wrs_transcribe_output* o
     const int64_t input_stride = WRS_N_FRAMES / m->T;                   // :120
     const double time_precision = (double)input_stride * kQuantum;      // :122
     OutBuilder ob;
+    ob.tok = dt.tokenizer;
     ob.tokens = prompt;  // :126-140
     int64_t seek = 0;
     const int tsb = dt.ids.ts_begin;
@@ -128,6 +142,7 @@ void TranscribeTask::run_chunked(const float* audio, int64_t n, int batch, wrs_t
     const int64_t input_stride = WRS_N_FRAMES / m->T;
     const double time_precision = (double)input_stride * kQuantum;
     OutBuilder ob;
+    ob.tok = dt.tokenizer;
     ob.tokens = prompt;
     const int tsb = dt.ids.ts_begin;
     dt.set_prompt(nullptr, 0);

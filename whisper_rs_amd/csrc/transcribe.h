@@ -13,6 +13,8 @@ struct TranscribeTask {
     MelWorkspace mel_ws;
     DevBuf audio_dev, mel_dev;
 
+    void set_tokenizer(const Tokenizer* tok) { dt.tokenizer = tok; }
+    void set_prompt_text(const char* utf8);  // TranscribePrompt::Text (transcribe.rs:130-134)
     void configure(Model* model, const wrs_token_ids& ids, const wrs_transcribe_options& o);
     int64_t prepare_mel(const float* audio, int64_t n);  // whole-file log-mel into mel_dev; returns frames
     void run(const float* audio, int64_t n, wrs_transcribe_output* out);
