@@ -1,7 +1,9 @@
 // Counterpart of reference examples/transcribe.rs on top of the C-ABI: same dims (base.en), same
-// option values (:44-60).  There are no checkpoints/audio in the build environment, so weights come
-// from a flat file of named fp32 tensors if given, else a deterministic LCG fill, and audio is a
-// 16-bit PCM WAV if given, else 35 s of synthetic tone+noise.
+// option values (:44-60), same flow: load weights -> tokenizer -> TranscribeTask -> load_audio -> run -> print.
+//   transcribe [audio.wav [tokenizer.json [weights.safetensors]]]
+// There are no checkpoints/audio in the build environment, so every input is optional: without a weights file the
+// model gets a deterministic pseudo-random fill, without a tokenizer file the output is token ids only (no text),
+// without a WAV the audio is 35 s of synthetic tone+noise.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -32,6 +34,12 @@ int main(int argc, char** argv) {
     wrs_model* model = nullptr;
     CK(wrs_model_create(&dims, 0, &model));
     uint32_t seed = 1;
+    if (argc > 3) {  // vars.load("weights.ot") (examples/transcribe.rs:37), safetensors container
+        int32_t n = 0;
+        CK(wrs_model_load_safetensors(model, argv[3], &n));
+        CK(wrs_model_finalize(model));
+        fprintf(stderr, "loaded model weights (%d tensors from %s)\n", n, argv[3]);
+    } else {
     const int64_t D = dims.n_audio_states;
     auto block = [&](const std::string& p, bool cross) -> int {
         int rc = 0;
@@ -74,8 +82,14 @@ int main(int argc, char** argv) {
     CK(set(model, "decoder.ln.bias", {D}, 0.1f, 0, seed));
     CK(wrs_model_finalize(model));
     fprintf(stderr, "loaded model weights (synthetic)\n");
+    }
 
     wrs_token_ids ids = {50256, 50257, 50357, 50358, 50359, 50360, 50361, 50362, 50363, 220};
+    wrs_tokenizer* tokenizer = nullptr;  // Tokenizer::new_from_file(Task::Transcribe, "tokenizer/gpt2.json") (:40)
+    if (argc > 2) {
+        CK(wrs_tokenizer_create_from_file(argv[2], &tokenizer));
+        CK(wrs_tokenizer_token_ids(tokenizer, &ids));
+    }
     static const int32_t non_speech[] = {1, 2, 7, 8, 9, 10, 14, 25, 26, 27, 28, 29, 31, 58, 59, 60, 61, 62, 63, 90, 91, 92, 93, 357, 366, 438, 532, 685, 705, 796, 930, 1058, 1220, 1267, 1279, 1303, 1343, 1377, 1391, 1635, 1782, 1875, 2162, 2361, 2488, 3467, 4008, 4211, 4600, 4808, 5299, 5855, 6329, 7203, 9609, 9959, 10563, 10786, 11420, 11709, 11907, 13163, 13697, 13700, 14808, 15306, 16410, 16791, 17992, 19203, 19510, 20724, 22305, 22935, 27007, 30109, 30420, 33409, 34949, 40283, 40493, 40549, 47282, 49146};
     wrs_transcribe_options opt;
     memset(&opt, 0, sizeof(opt));
@@ -96,23 +110,16 @@ int main(int argc, char** argv) {
     opt.condition_on_prev_text = 1;                          // TranscribePrompt::None { condition_on_prev_text: true }
     wrs_transcribe_task* task = nullptr;
     CK(wrs_transcribe_task_create(model, &ids, &opt, &task));
+    if (tokenizer) CK(wrs_transcribe_task_set_tokenizer(task, tokenizer));
     fprintf(stderr, "initialized transcription task\n");
 
     std::vector<float> audio;
-    if (argc > 1) {
-        FILE* f = fopen(argv[1], "rb");
-        if (!f) { perror(argv[1]); return 1; }
-        std::vector<unsigned char> raw;
-        unsigned char buf[65536];
-        size_t n;
-        while ((n = fread(buf, 1, sizeof(buf), f)) > 0) raw.insert(raw.end(), buf, buf + n);
-        fclose(f);
-        size_t pos = 12;  // RIFF....WAVE ; find "data" chunk, assume 16 kHz mono s16le
-        while (pos + 8 <= raw.size() && memcmp(&raw[pos], "data", 4) != 0) pos += 8 + (raw[pos + 4] | raw[pos + 5] << 8 | raw[pos + 6] << 16 | raw[pos + 7] << 24);
-        if (pos + 8 > raw.size()) { fprintf(stderr, "no data chunk\n"); return 1; }
-        const size_t bytes = raw[pos + 4] | raw[pos + 5] << 8 | raw[pos + 6] << 16 | (size_t)raw[pos + 7] << 24;
-        for (size_t i = pos + 8; i + 1 < std::min(raw.size(), pos + 8 + bytes); i += 2)
-            audio.push_back((int16_t)(raw[i] | raw[i + 1] << 8) / 32768.0f);
+    if (argc > 1) {  // whisper::audio::load_audio(path) (:65)
+        float* samples = nullptr;
+        int64_t n = 0;
+        CK(wrs_load_audio(argv[1], &samples, &n));
+        audio.assign(samples, samples + n);
+        wrs_audio_free(samples);
     } else {
         audio.resize(16000 * 35);
         for (size_t i = 0; i < audio.size(); ++i)
@@ -122,11 +129,14 @@ int main(int argc, char** argv) {
     wrs_transcribe_output out;
     CK(wrs_transcribe_task_run(task, audio.data(), (int64_t)audio.size(), &out));
     printf("transcribed audio: %ld tokens, %ld segments\n", (long)out.n_tokens, (long)out.n_segments);
+    if (out.text) printf("text: %s\n", out.text);
     for (int64_t i = 0; i < out.n_segments; ++i)
-        printf("  segment seek=%ld [%.2f, %.2f] tokens %ld..%ld\n", (long)out.segments[i].seek, out.segments[i].start_time,
-               out.segments[i].end_time, (long)out.segments[i].start_token, (long)out.segments[i].end_token);
+        printf("  segment seek=%ld [%.2f, %.2f] tokens %ld..%ld%s%s\n", (long)out.segments[i].seek, out.segments[i].start_time,
+               out.segments[i].end_time, (long)out.segments[i].start_token, (long)out.segments[i].end_token,
+               out.segments[i].text ? " text: " : "", out.segments[i].text ? out.segments[i].text : "");
     wrs_transcribe_output_free(&out);
     wrs_transcribe_task_destroy(task);
+    wrs_tokenizer_destroy(tokenizer);
     wrs_model_destroy(model);
     return 0;
 }

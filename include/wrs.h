@@ -78,6 +78,10 @@ int wrs_model_create(const wrs_model_dims* dims, int device_id, wrs_model** out)
  * converted to fp16 for the MFMA path (LayerNorm/bias/positional tensors stay fp32). */
 int wrs_model_set_tensor(wrs_model* m, const char* name, int dtype, const int64_t* shape, int ndim,
                          const void* data, int mem_kind);
+/* `vars.load("weights.ot")` from a file: the same named tensors in safetensors format (F32, F16 or BF16; `.ot` is tch's
+ * pickle-based archive, not read here — scripts/convert_checkpoint.py converts).  Tensors of other names are ignored;
+ * *n_loaded (optional) = tensors taken.  Call wrs_model_finalize afterwards. */
+int wrs_model_load_safetensors(wrs_model* m, const char* path, int32_t* n_loaded);
 /* checks every tensor of the manifest is present and builds the fused/packed device layouts. */
 int wrs_model_finalize(wrs_model* m);
 /* `Whisper::device()` (model.rs:601-603): HIP device ordinal. */
@@ -107,6 +111,15 @@ int wrs_model_clear_cache(wrs_model* m);
 
 /* ---------------------------------------------------------------- audio (src/audio.rs) */
 
+/* `audio::load_audio(path)` (audio.rs:20-173) for RIFF/WAVE files (PCM 8/16/24/32-bit, IEEE float 32/64): decode,
+ * downmix to mono by the channel mean (:121-127), resample to 16 kHz when the file's rate differs (:72-88).  The
+ * reference resamples with rubato's FftFixedIn (third-party, not vendored): resampled output is band-limited to the
+ * same Nyquist but not sample-identical (parity unpinned); 16 kHz files are bit-exact.  Other containers are out of
+ * scope (WRS_EINVAL).  *out is library-owned: release with wrs_audio_free.  Host-only. */
+int wrs_load_audio(const char* path, float** out, int64_t* n_samples);
+/* the resampler alone: rate_in -> rate_out, n_out = ceil(n * rate_out / rate_in) */
+int wrs_resample(const float* in, int64_t n, int32_t rate_in, int32_t rate_out, float** out, int64_t* n_out);
+void wrs_audio_free(float* p);
 /* `audio::mel_filter()` (audio.rs:175-188): out[80*201] row-major f32. */
 int wrs_mel_filter(float* out);
 /* `audio::pad_or_trim(x, len)` (audio.rs:213-228) on the last dim of a [rows, n] f32 array. */

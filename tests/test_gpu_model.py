@@ -70,3 +70,24 @@ def test_decoder_forward_errors(gpu):
     with pytest.raises(gpu.WrsError):  # positional overflow (reference panics slicing positional_embedding)
         gm.decoder_forward_ext(np.zeros((1, 2), np.int64), np.zeros((1, 1500, dims.n_text_states), np.float32), dims.n_text_ctxs - 1)
     gm.clear_cache()
+
+
+def test_weights_file_loader_equals_set_tensor(gpu, tmp_path):
+    """`vars.load(file)` (examples/transcribe.rs:37): a safetensors file of the VarStore-named tensors (F32 and F16 mixed,
+    plus a tensor the architecture does not have) gives the same model as wrs_model_set_tensor."""
+    from safetensors.numpy import save_file
+    from helpers import weights
+    w = weights("nano")
+    on_disk = {k: (v.astype(np.float16) if v.ndim == 2 and "embedding" not in k else v) for k, v in w.items()}
+    on_disk["encoder.positional_embedding"] = np.zeros((1500, MODEL_DIMS["nano"].n_audio_states), np.float32)  # OpenAI buffer: ignored
+    path = tmp_path / "nano.safetensors"
+    save_file(on_disk, str(path))
+    m = gpu.Whisper(MODEL_DIMS["nano"])
+    assert m.load_file(path) == len(w)
+    ref = gpu.Whisper(MODEL_DIMS["nano"], {k: (v.astype(np.float16).astype(np.float32) if v.ndim == 2 and "embedding" not in k else v) for k, v in w.items()})
+    mel = mel_windows(1)
+    np.testing.assert_array_equal(m.encoder_forward(mel), ref.encoder_forward(mel))
+    m2 = gpu.Whisper(MODEL_DIMS["nano"])
+    with pytest.raises(gpu.WrsError):
+        m2.load_file(tmp_path / "missing.safetensors")
+    m.close(); ref.close(); m2.close()

@@ -76,6 +76,7 @@ SYMBOLS = {
     "wrs_device_count": (C.c_int, []),
     "wrs_model_create": (C.c_int, [P(ModelDimsC), C.c_int, P(C.c_void_p)]),
     "wrs_model_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, P(C.c_int64), C.c_int, C.c_void_p, C.c_int]),
+    "wrs_model_load_safetensors": (C.c_int, [C.c_void_p, C.c_char_p, P(C.c_int32)]),
     "wrs_model_finalize": (C.c_int, [C.c_void_p]),
     "wrs_model_device": (C.c_int, [C.c_void_p]),
     "wrs_model_get_dims": (C.c_int, [C.c_void_p, P(ModelDimsC)]),
@@ -84,6 +85,9 @@ SYMBOLS = {
     "wrs_decoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "wrs_model_update_cache": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "wrs_model_clear_cache": (C.c_int, [C.c_void_p]),
+    "wrs_load_audio": (C.c_int, [C.c_char_p, P(P(C.c_float)), P(C.c_int64)]),
+    "wrs_resample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, P(P(C.c_float)), P(C.c_int64)]),
+    "wrs_audio_free": (None, [P(C.c_float)]),
     "wrs_mel_filter": (C.c_int, [C.c_void_p]),
     "wrs_pad_or_trim": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "wrs_log_mel_spectrogram": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]),

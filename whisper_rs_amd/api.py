@@ -35,6 +35,28 @@ class audio:
     """reference `whisper::audio` (src/audio.rs)."""
 
     @staticmethod
+    def load_audio(path) -> np.ndarray:
+        """`audio::load_audio(path)` (audio.rs:20-173) for WAV files: mono f32 at 16 kHz."""
+        lib = L.load()
+        p, n = C.POINTER(C.c_float)(), C.c_int64()
+        L.check(lib.wrs_load_audio(str(path).encode(), C.byref(p), C.byref(n)))
+        try:
+            return np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)
+        finally:
+            lib.wrs_audio_free(p)
+
+    @staticmethod
+    def resample(x: np.ndarray, rate_in: int, rate_out: int = 16000) -> np.ndarray:
+        lib = L.load()
+        x = _f32(x)
+        p, n = C.POINTER(C.c_float)(), C.c_int64()
+        L.check(lib.wrs_resample(_ptr(x), x.shape[0], rate_in, rate_out, C.byref(p), C.byref(n)))
+        try:
+            return np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)
+        finally:
+            lib.wrs_audio_free(p)
+
+    @staticmethod
     def mel_filter() -> np.ndarray:
         out = np.empty((N_MELS, 201), dtype=np.float32)
         L.check(L.load().wrs_mel_filter(_ptr(out)))
@@ -179,6 +201,14 @@ class Whisper:
 
     def finalize(self):
         L.check(self._lib.wrs_model_finalize(self._h))
+
+    def load_file(self, path) -> int:
+        """`vars.load("weights.ot")` (examples/transcribe.rs:37) from a safetensors file of the same named tensors;
+        returns the number of tensors taken and finalizes the model."""
+        n = C.c_int32()
+        L.check(self._lib.wrs_model_load_safetensors(self._h, str(path).encode(), C.byref(n)))
+        L.check(self._lib.wrs_model_finalize(self._h))
+        return n.value
 
     def device(self):
         return self._lib.wrs_model_device(self._h)

@@ -1,6 +1,7 @@
 // extern "C" surface of libwrs_mi355x.so — see include/wrs.h for the reference interface each
 // entry replaces.  No exceptions cross this boundary; no torch types appear in it.
 #include "transcribe.h"
+#include "audio_io.h"
 #include <map>
 #include <mutex>
 #include <fstream>
@@ -53,6 +54,13 @@ int wrs_model_set_tensor(wrs_model* m, const char* name, int dtype, const int64_
     return guarded([&] {
         WRS_REQUIRE(m && name, "wrs_model_set_tensor: null argument");
         m->m.set_tensor(name, dtype, shape, ndim, data, mem_kind);
+    });
+}
+int wrs_model_load_safetensors(wrs_model* m, const char* path, int32_t* n_loaded) {
+    return guarded([&] {
+        WRS_REQUIRE(m && path, "wrs_model_load_safetensors: null argument");
+        const int n = load_safetensors(m->m, path);
+        if (n_loaded) *n_loaded = n;
     });
 }
 int wrs_model_finalize(wrs_model* m) {
@@ -336,6 +344,30 @@ int wrs_filter_topk(wrs_decode_task* t, const float* logits, const int64_t* toke
 int wrs_decode_task_set_tokenizer(wrs_decode_task* t, const wrs_tokenizer* tok) {
     return guarded([&] { WRS_REQUIRE(t, "null task"); t->t.tokenizer = tok ? &tok->t : nullptr; });
 }
+
+// ------------------------------------------------------------------ audio ingest (host only)
+static float* dup_samples(const std::vector<float>& v) {
+    float* p = (float*)malloc(std::max<size_t>(1, v.size()) * sizeof(float));
+    memcpy(p, v.data(), v.size() * sizeof(float));
+    return p;
+}
+int wrs_load_audio(const char* path, float** out, int64_t* n_samples) {
+    return guarded([&] {
+        WRS_REQUIRE(path && out && n_samples, "wrs_load_audio: null argument");
+        const std::vector<float> a = load_audio_file(path);
+        *out = dup_samples(a);
+        *n_samples = (int64_t)a.size();
+    });
+}
+int wrs_resample(const float* in, int64_t n, int32_t rate_in, int32_t rate_out, float** out, int64_t* n_out) {
+    return guarded([&] {
+        WRS_REQUIRE((in || n == 0) && out && n_out, "wrs_resample: null argument");
+        const std::vector<float> a = resample_f32(in, n, rate_in, rate_out);
+        *out = dup_samples(a);
+        *n_out = (int64_t)a.size();
+    });
+}
+void wrs_audio_free(float* p) { free(p); }
 
 // ------------------------------------------------------------------ tokenizer (host only)
 int wrs_tokenizer_create_from_bytes(const void* bytes, size_t n_bytes, wrs_tokenizer** out) {

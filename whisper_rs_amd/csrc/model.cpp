@@ -74,7 +74,7 @@ void Model::collect_cross_events(int n_audio) {
 
 void Model::use() const { HIP_CHECK(hipSetDevice(device)); }
 
-static bool expected_shape(const Model& m, const std::string& name, std::vector<int64_t>& shape) {
+bool expected_shape(const Model& m, const std::string& name, std::vector<int64_t>& shape) {
     const int64_t D = m.dims.n_audio_states, Dt = m.dims.n_text_states;
     auto ends = [&](const char* suf) {
         const size_t n = strlen(suf);

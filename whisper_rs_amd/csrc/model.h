@@ -176,4 +176,9 @@ struct Timed {
     }
 };
 
+// shape the architecture expects for a VarStore path; false for names the model does not have
+bool expected_shape(const Model& m, const std::string& name, std::vector<int64_t>& shape);
+// weights_io.cpp: reads every tensor of the architecture found in a safetensors file; returns how many were set
+int load_safetensors(Model& m, const char* path);
+
 }  // namespace wrs
