@@ -238,6 +238,14 @@ int wrs_decode_task_run_features(wrs_decode_task* t, const float* audio_features
 /* same, starting from raw audio windows [n_audio, 480000] f32: mel (per-window max) + run. */
 int wrs_decode_task_run_audio(wrs_decode_task* t, const float* audio, int32_t n_audio, int mem_kind,
                               wrs_decode_result* result);
+/* Overlapped mode (beyond the reference, whose loop is sequential: the unit that keeps a GPU's work queue full).
+ * encode_async queues log-mel + AudioEncoder + cross-attention K/V projection of a batch of raw audio windows
+ * ([n_audio, 480000] f32) on a side stream and returns at once; run_pending decodes the OLDEST queued batch.  Calling
+ * encode_async for batch i+1 right before run_pending for batch i overlaps the MFMA-bound encoder of one batch with the
+ * HBM-bound decode steps of the other (two cross-K/V buffers; at most two batches queued).  A device `audio` buffer must
+ * stay valid until the batch has been decoded.  Results are identical to wrs_decode_task_run_audio. */
+int wrs_decode_task_encode_async(wrs_decode_task* t, const float* audio, int32_t n_audio, int mem_kind);
+int wrs_decode_task_run_pending(wrs_decode_task* t, wrs_decode_result* result);
 /* same, on the windows whose encoder output is still resident from the previous run / detect call of this task's model */
 int wrs_decode_task_run_encoded(wrs_decode_task* t, int32_t n_audio, wrs_decode_result* result);
 /* Language identification (the reference declares `Task::LanguageId`, tokenize.rs:135-139, without implementing it;

@@ -232,3 +232,39 @@ def test_large_batch_gemm_path_teacher_forced(gpu, monkeypatch):
     finally:
         monkeypatch.delenv("WRS_DEC_BIG_GEMM_ROWS")
         helpers._gpu_models.pop(("micro", 0, ()), None)
+
+
+def test_overlapped_mode_equals_sequential(gpu):
+    """wrs_decode_task_encode_async / run_pending (encoder of the next batch on a side stream, two cross-K/V buffers)
+    return exactly what run_audio returns, batch after batch, in FIFO order."""
+    from whisper_rs_amd import synth
+    gm = gpu_model(gpu, "micro")
+    batches = [synth.make_audio(2, seed=500 + 10 * i) for i in range(4)]
+    ref_task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=14, max_audio=2))
+    want = [ref_task.run_audio(b) for b in batches]
+    ref_task.close()
+    task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=14, max_audio=2))
+    got = []
+    task.encode_async(batches[0])
+    for i in range(len(batches)):
+        if i + 1 < len(batches):
+            task.encode_async(batches[i + 1])
+        got.append(task.run_pending())
+    for w, g in zip(want, got):
+        for a, b in zip(w, g):
+            np.testing.assert_array_equal(a.tokens, b.tokens)
+            assert a.sum_logprob == b.sum_logprob and a.no_speech_prob == b.no_speech_prob
+    # misuse is refused, and the sequential entry still works afterwards
+    with pytest.raises(gpu.WrsError):
+        task.run_pending()
+    task.encode_async(batches[0]); task.encode_async(batches[1])
+    with pytest.raises(gpu.WrsError):
+        task.encode_async(batches[2])
+    with pytest.raises(gpu.WrsError):
+        task.run_audio(batches[0])
+    a = task.run_pending(); b = task.run_pending()
+    np.testing.assert_array_equal(a[0].tokens, want[0][0].tokens)
+    np.testing.assert_array_equal(b[1].tokens, want[1][1].tokens)
+    again = task.run_audio(batches[2])
+    np.testing.assert_array_equal(again[0].tokens, want[2][0].tokens)
+    task.close()

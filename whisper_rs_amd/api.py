@@ -387,6 +387,25 @@ class DecodeTask:
         L.check(self._lib.wrs_decode_task_run_audio(self._h, _ptr(a), a.shape[0], L.WRS_MEM_HOST, C.byref(res)))
         return self._collect(res)
 
+    def encode_async(self, audio_, n_audio: Optional[int] = None):
+        """queue mel + encoder + cross-K/V of a window batch on the side stream (overlapped mode).  audio_: numpy
+        [n, 480000] (host) or a device pointer (int) with n_audio given; a device buffer must outlive the batch."""
+        if isinstance(audio_, int):
+            L.check(self._lib.wrs_decode_task_encode_async(self._h, C.c_void_p(audio_), n_audio, L.WRS_MEM_DEVICE))
+            return
+        a = _f32(audio_)
+        assert a.ndim == 2 and a.shape[1] == N_SAMPLES
+        L.check(self._lib.wrs_decode_task_encode_async(self._h, _ptr(a), a.shape[0], L.WRS_MEM_HOST))
+        # host buffers are copied by an asynchronous H2D on the side stream: keep `a` alive until run_pending
+        self._keep_async = getattr(self, "_keep_async", []) + [a]
+
+    def run_pending(self) -> List[DecodeOutput]:
+        res = L.DecodeResultC()
+        L.check(self._lib.wrs_decode_task_run_pending(self._h, C.byref(res)))
+        if getattr(self, "_keep_async", None):
+            self._keep_async.pop(0)
+        return self._collect(res)
+
     def run_encoded(self, n_audio: int) -> List[DecodeOutput]:
         """decode the windows whose encoder output is still resident (after detect_language / a previous run)."""
         res = L.DecodeResultC()

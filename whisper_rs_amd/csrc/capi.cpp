@@ -45,7 +45,11 @@ int wrs_model_create(const wrs_model_dims* dims, int device_id, wrs_model** out)
         h->m.dims = *dims;
         h->m.device = device_id;
         HIP_CHECK(hipSetDevice(device_id));
-        HIP_CHECK(hipStreamCreateWithFlags(&h->m.stream, hipStreamNonBlocking));
+        // highest stream priority: the decode steps are a chain of short dependent kernels; work queued on a task's side
+        // stream (overlapped mode, lowest priority) fills the CUs they leave idle instead of delaying them
+        int prio_least = 0, prio_greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&h->m.stream, hipStreamNonBlocking, prio_greatest));
         h->m.timer = new StageTimer();
         *out = h.release();
     });
@@ -223,6 +227,7 @@ int wrs_decode_task_set_prompt(wrs_decode_task* t, const int64_t* prompt, int32_
 }
 int wrs_decode_task_run(wrs_decode_task* t, const float* mel, int32_t n_audio, int mem_kind, wrs_decode_result* result) {
     return guarded([&] {
+        WRS_REQUIRE(t && t->t.pending.empty(), "batches queued with wrs_decode_task_encode_async must be decoded (wrs_decode_task_run_pending) first");
         WRS_REQUIRE(t && mel && result, "wrs_decode_task_run: null argument");
         WRS_REQUIRE(n_audio >= 1 && n_audio <= t->t.max_audio, "wrs_decode_task_run: %d windows exceed capacity %d", n_audio, t->t.max_audio);
         Model& m = *t->t.m;
@@ -233,6 +238,7 @@ int wrs_decode_task_run(wrs_decode_task* t, const float* mel, int32_t n_audio, i
 }
 int wrs_decode_task_run_features(wrs_decode_task* t, const float* feats, int32_t n_audio, int mem_kind, wrs_decode_result* result) {
     return guarded([&] {
+        WRS_REQUIRE(t && t->t.pending.empty(), "batches queued with wrs_decode_task_encode_async must be decoded (wrs_decode_task_run_pending) first");
         WRS_REQUIRE(t && feats && result, "wrs_decode_task_run_features: null argument");
         WRS_REQUIRE(n_audio >= 1 && n_audio <= t->t.max_audio, "wrs_decode_task_run_features: %d windows exceed capacity %d", n_audio, t->t.max_audio);
         Model& m = *t->t.m;
@@ -247,6 +253,7 @@ int wrs_decode_task_run_features(wrs_decode_task* t, const float* feats, int32_t
 }
 int wrs_decode_task_run_audio(wrs_decode_task* t, const float* audio, int32_t n_audio, int mem_kind, wrs_decode_result* result) {
     return guarded([&] {
+        WRS_REQUIRE(t && t->t.pending.empty(), "batches queued with wrs_decode_task_encode_async must be decoded (wrs_decode_task_run_pending) first");
         WRS_REQUIRE(t && audio && result, "wrs_decode_task_run_audio: null argument");
         WRS_REQUIRE(n_audio >= 1 && n_audio <= t->t.max_audio, "wrs_decode_task_run_audio: %d windows exceed capacity %d", n_audio, t->t.max_audio);
         DecodeTask& d = t->t;
@@ -267,6 +274,12 @@ int wrs_decode_task_run_audio(wrs_decode_task* t, const float* audio, int32_t n_
         d.run_loaded(n_audio, result);
     });
 }
+int wrs_decode_task_encode_async(wrs_decode_task* t, const float* audio, int32_t n_audio, int mem_kind) {
+    return guarded([&] { WRS_REQUIRE(t && audio, "wrs_decode_task_encode_async: null argument"); t->t.encode_async(audio, n_audio, mem_kind); });
+}
+int wrs_decode_task_run_pending(wrs_decode_task* t, wrs_decode_result* result) {
+    return guarded([&] { WRS_REQUIRE(t && result, "wrs_decode_task_run_pending: null argument"); t->t.run_pending(result); });
+}
 int wrs_decode_task_run_encoded(wrs_decode_task* t, int32_t n_audio, wrs_decode_result* result) {
     return guarded([&] {
         WRS_REQUIRE(t && result, "wrs_decode_task_run_encoded: null argument");
@@ -278,6 +291,7 @@ int wrs_decode_task_run_encoded(wrs_decode_task* t, int32_t n_audio, wrs_decode_
 int wrs_decode_task_detect_language(wrs_decode_task* t, const float* mel, int32_t n_audio, int mem_kind, int32_t first_language_id,
                                     int32_t n_languages, int32_t* out_language_ids, float* out_probs) {
     return guarded([&] {
+        WRS_REQUIRE(t && t->t.pending.empty(), "batches queued with wrs_decode_task_encode_async must be decoded (wrs_decode_task_run_pending) first");
         WRS_REQUIRE(t && mel && out_language_ids, "wrs_decode_task_detect_language: null argument");
         WRS_REQUIRE(n_audio >= 1 && n_audio <= t->t.max_audio, "wrs_decode_task_detect_language: %d windows exceed capacity %d", n_audio, t->t.max_audio);
         Model& m = *t->t.m;

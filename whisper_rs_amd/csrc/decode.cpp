@@ -22,6 +22,75 @@ static double round_half_away(double x) { return x >= 0 ? std::floor(x + 0.5) : 
 DecodeTask::~DecodeTask() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    for (auto& e : side_done) if (e) (void)hipEventDestroy(e);
+}
+
+bool DecodeTask::side_idle() {
+    if (!side) return true;
+    const hipError_t e = hipStreamQuery(side);
+    if (e == hipSuccess) return true;
+    if (e != hipErrorNotReady) HIP_CHECK(e);
+    (void)hipGetLastError();
+    return false;
+}
+
+// Queue log-mel, AudioEncoder and the cross-attention K/V projection of a window batch on the side stream, into the
+// cross-K/V buffer the decode steps are not reading.  The MFMA-bound encoder of batch i+1 then overlaps the HBM-bound
+// decode steps of batch i.  The encoder workspace is single: queued batches run one after the other on the side stream.
+void DecodeTask::encode_async(const float* audio, int n_audio, int mem_kind) {
+    WRS_REQUIRE(audio && n_audio >= 1 && n_audio <= max_audio, "encode_async: %d windows exceed the task capacity %d", n_audio, max_audio);
+    WRS_REQUIRE(pending.size() < 2, "encode_async: two batches are already queued (call run_pending first)");
+    m->use();
+    if (!side) {
+        int prio_least = 0, prio_greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_least));
+        for (auto& e : side_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        st.cross_kp2.alloc(st.cross_kp.bytes);
+        st.cross_vp2.alloc(st.cross_vp.bytes);
+    }
+    // the buffer that is neither queued nor (if nothing is queued) the one the last decode read: decode is synchronous
+    // on the host, so no decode step is in flight here
+    const int buf = pending.empty() ? (st.cross_sel ^ 1) : (pending.back().buf ^ 1);
+    hipStream_t main_stream = m->stream;
+    m->stream = side;  // every launch helper of the model enqueues on m->stream
+    try {
+        const float* a_d = audio;
+        if (mem_kind == WRS_MEM_HOST) {
+            audio_dev.ensure((size_t)n_audio * WRS_N_SAMPLES * 4);
+            HIP_CHECK(hipMemcpyAsync(audio_dev.p, audio, (size_t)n_audio * WRS_N_SAMPLES * 4, hipMemcpyHostToDevice, side));
+            a_d = audio_dev.as<float>();
+        }
+        mel_dev.ensure((size_t)n_audio * 80 * WRS_N_FRAMES * 4);
+        log_mel_device(mel_ws, a_d, n_audio, WRS_N_SAMPLES, nullptr, mel_dev.as<float>(), side);
+        m->load_mel(mel_dev.as<float>(), n_audio, WRS_MEM_DEVICE, WRS_N_FRAMES, 0);
+        m->encoder_from_mel_t(n_audio);
+        st.cross_wsel = buf;
+        m->load_cross_kv(st, m->enc_ws.xa16.as<half_t>(), n_audio);
+        st.cross_wsel = st.cross_sel;
+        HIP_CHECK(hipEventRecord(side_done[buf], side));
+    } catch (...) {
+        m->stream = main_stream;
+        st.cross_wsel = st.cross_sel;
+        throw;
+    }
+    m->stream = main_stream;
+    pending.push_back({buf, n_audio});
+}
+
+void DecodeTask::run_pending(wrs_decode_result* out) {
+    WRS_REQUIRE(out, "run_pending: null result");
+    WRS_REQUIRE(!pending.empty(), "run_pending: nothing queued (call encode_async first)");
+    m->use();
+    const Pending pd = pending.front();
+    pending.erase(pending.begin());
+    const double t0 = now_ms();
+    HIP_CHECK(hipEventSynchronize(side_done[pd.buf]));  // host-visible part of the encoder time (what was not hidden)
+    st.cross_sel = st.cross_wsel = pd.buf;
+    st.n_audio = pd.n_audio;
+    run_decode(pd.n_audio, out);
+    t_encoder_ms = now_ms() - t0 - (t_prefill_ms + t_steps_ms + t_host_ms);
 }
 
 void DecodeTask::configure(Model* model, const wrs_token_ids& tid, const wrs_decode_options& o) {
@@ -160,9 +229,11 @@ void DecodeTask::step_decode(int R) {
                            st.no_speech_d(), nullptr, m->stream);
     };
     const bool profiling = m->timer && m->timer->enabled;
-    const bool sample_now = m->cross_ev_enabled && (m->cross_ev_step++ % m->cross_ev_every == 0);
+    // roofline sampling: every n-th step is launched eagerly with event pairs around the cross-attention kernel; in
+    // overlapped mode only while no encoder work is queued on the side stream, so a sample is the kernel's own duration
+    const bool sample_now = m->cross_ev_enabled && (m->cross_ev_step++ % m->cross_ev_every == 0) && side_idle();
     if (use_graph && !profiling && !sample_now) {
-        if (!graph_exec || graph_rows != R) {
+        if (!graph_exec || graph_rows != R || graph_sel != st.cross_sel) {
             if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
             if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
             HIP_CHECK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
@@ -177,6 +248,7 @@ void DecodeTask::step_decode(int R) {
             HIP_CHECK(hipStreamEndCapture(m->stream, &graph));
             HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
             graph_rows = R;
+            graph_sel = st.cross_sel;
         }
         HIP_CHECK(hipGraphLaunch(graph_exec, m->stream));
         HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -308,13 +380,23 @@ void DecodeTask::run_encoded(int n_audio, wrs_decode_result* out) {
     WRS_REQUIRE(S <= m->n_ctx, "prompt of %d tokens exceeds n_text_ctxs %d (the reference panics slicing positional_embedding)", S, m->n_ctx);
     hipStream_t s = m->stream;
 
+    WRS_REQUIRE(pending.empty(), "run: batches queued with encode_async must be decoded (run_pending) first");
     double tA = now_ms();
+    st.cross_wsel = st.cross_sel;
     m->load_cross_kv(st, m->enc_ws.xa16.as<half_t>(), n_audio);
-    launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m->n_ctx, m->n_ctx, st.r_cap, G, s);
     HIP_CHECK(hipStreamSynchronize(s));  // attribute encoder + cross-K/V time (everything queued so far)
-    t_encoder_ms = now_ms() - tA;
+    run_decode(n_audio, out);
+    t_encoder_ms = now_ms() - tA - (t_prefill_ms + t_steps_ms + t_host_ms);
+}
+
+void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
+    memset(out, 0, sizeof(*out));
+    const int G = group, R = n_audio * G, S = sample_begin;
+    WRS_REQUIRE(S <= m->n_ctx, "prompt of %d tokens exceeds n_text_ctxs %d (the reference panics slicing positional_embedding)", S, m->n_ctx);
+    hipStream_t s = m->stream;
+    launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m->n_ctx, m->n_ctx, st.r_cap, G, s);
     t_prefill_ms = t_steps_ms = t_host_ms = 0;
-    tA = now_ms();
+    double tA = now_ms();
 
     // host state (decode/mod.rs:297-325)
     rows.assign(R, initial_tokens);

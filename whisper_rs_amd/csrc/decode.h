@@ -61,7 +61,14 @@ struct DecodeTask {
     bool use_graph = true;
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;
-    int graph_rows = -1;
+    int graph_rows = -1, graph_sel = -1;  // the captured step reads the cross K/V buffer `graph_sel`
+
+    // overlapped mode: mel + encoder + cross-K/V projection of up to two window batches queued on a side stream
+    hipStream_t side = nullptr;
+    hipEvent_t side_done[2] = {nullptr, nullptr};
+    struct Pending { int buf, n_audio; };
+    std::vector<Pending> pending;  // FIFO, oldest first
+    bool side_idle();              // every queued encode has finished on the device
 
     ~DecodeTask();
     void configure(Model* model, const wrs_token_ids& ids, const wrs_decode_options& o);
@@ -72,6 +79,12 @@ struct DecodeTask {
     void run_loaded(int n_audio, wrs_decode_result* out);
     // encoder output already in m->enc_ws.xa16/xa32
     void run_encoded(int n_audio, wrs_decode_result* out);
+    // cross K/V of the batch already in st's buffer `st.cross_sel` (queued work waited for by the caller)
+    void run_decode(int n_audio, wrs_decode_result* out);
+    // overlapped mode (beyond the reference, whose loop is sequential): queue mel/encoder/cross-K/V of a batch of raw
+    // audio windows on the side stream and return; run_pending decodes the oldest queued batch on the main stream
+    void encode_async(const float* audio, int n_audio, int mem_kind);
+    void run_pending(wrs_decode_result* out);
     // test hook: follow externally given beam decisions (tokens/sources per step) and return the device's raw
     // per-step top-k candidates; the window batch must already be in m->enc_ws.mel_t
     // language identification on the encoder output in m->enc_ws.xa16 (OpenAI detect_language)

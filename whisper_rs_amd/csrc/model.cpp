@@ -453,8 +453,8 @@ void Model::load_cross_kv(DecState& st, const half_t* xa16, int n_audio) {
         }
         {
             Timed tm(timer, "dec_cross_kv_pack", stream, (double)M * D * 2 * 2 * 2);
-            launch_pack_kv(st.ckv_tmp.as<half_t>(), 2 * D, 0, D, n_audio, T, H, st.cross_kp.as<half_t>() + l * per_layer,
-                           st.cross_vp.as<half_t>() + l * per_layer, stream);
+            launch_pack_kv(st.ckv_tmp.as<half_t>(), 2 * D, 0, D, n_audio, T, H, st.ckp(st.cross_wsel) + l * per_layer,
+                           st.cvp(st.cross_wsel) + l * per_layer, stream);
         }
     }
     st.n_audio = n_audio;
@@ -543,8 +543,8 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
                 while ((int)cross_ev.size() < 2 * (slot + 1)) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); cross_ev.push_back(e); }
                 HIP_CHECK(hipEventRecord(cross_ev[2 * slot], stream));
             }
-            launch_attn_cross(slab, ks_d, mp, b.cq_b, scale, st.cross_kp.as<half_t>() + l * cross_layer,
-                              st.cross_vp.as<half_t>() + l * cross_layer, n_audio, q_per_audio, T, H, st.att.as<half_t>(), stream);
+            launch_attn_cross(slab, ks_d, mp, b.cq_b, scale, st.ckp(st.cross_sel) + l * cross_layer,
+                              st.cvp(st.cross_sel) + l * cross_layer, n_audio, q_per_audio, T, H, st.att.as<half_t>(), stream);
             if (sample) HIP_CHECK(hipEventRecord(cross_ev[2 * slot + 1], stream));
         }
         gemm_slab("dec_gemm_out", st.att.as<half_t>(), b.cout_w, D, D, ks_d, wD);

@@ -38,6 +38,13 @@ struct DecState {
     int a_cap = 0, group = 1, r_cap = 0, m_pad = 0, act_rows = 0, logits_ld = 0;
     int n_audio = 0;  // audios whose cross K/V are loaded
     DevBuf cross_kp, cross_vp;  // [L][a_cap][H][Tp*64]
+    // second cross-attention K/V buffer (allocated on first use by the overlapped mode: the next window batch's encoder
+    // and K/V projection run on a side stream while this batch's decode steps read the other buffer)
+    DevBuf cross_kp2, cross_vp2;
+    int cross_sel = 0;   // buffer the decode steps read
+    int cross_wsel = 0;  // buffer load_cross_kv writes
+    half_t* ckp(int sel) const { return (sel ? cross_kp2 : cross_kp).as<half_t>(); }
+    half_t* cvp(int sel) const { return (sel ? cross_vp2 : cross_vp).as<half_t>(); }
     DevBuf kc, vc;              // [L][r_cap][n_ctx][D]
     DevBuf anc;                 // [2][r_cap][n_ctx]
     DevBuf x, xn, att, h, slab, logits, ckv_tmp;
