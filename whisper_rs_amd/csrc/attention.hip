@@ -101,6 +101,9 @@ struct AttnParams {
 #ifndef XA_WAVES
 #define XA_WAVES 8   // waves per workgroup in the SPLIT (decode cross-attention) kernel (measured: 2/4/8/12/16 -> 90/94/77-82/90/95 us)
 #endif
+#ifndef ENC_ATTN_NQ
+#define ENC_ATTN_NQ 2  // query tiles per wave in the encoder attention (measured 1 / 2 / 4: 392 / 408 / 300 TFLOP/s; 4 drops to one wave per SIMD)
+#endif
 #ifndef XA_NT
 #define XA_NT 1      // non-temporal K/V loads in the SPLIT kernel: every byte is read once per launch (measured -6 us)
 #endif
@@ -112,8 +115,11 @@ __device__ __forceinline__ half8 kv_load(const half_t* ptr) {
     return *reinterpret_cast<const half8*>(ptr);
 }
 
-template <bool SPLIT>
+// NQ (encoder only): query tiles of 16 per wave; every K/V fragment fetched is used NQ times from registers.  The kernel
+// turned out to be bound by the softmax VALU work per (query tile, key block), not by the loads: NQ = 2 gains 4 %.
+template <bool SPLIT, int NQ>
 __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(const AttnParams p) {
+    static_assert(!SPLIT || NQ == 1, "the decode kernel has one query tile (the beams of an audio)");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int h, b, qblk = 0;
     if (SPLIT) {
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
     } else {
         // 1-D grid, XCD-aware: all query blocks of one (batch, head) run on ONE XCD so its packed K/V (384 KiB) is
         // fetched into one L2 once instead of by all 8 (measured FETCH_SIZE 8x the K/V bytes before).  Speed only.
-        const int wq = (p.q_rows_per_batch + 63) >> 6;     // query blocks per (batch, head)
+        const int wq = (p.q_rows_per_batch + 64 * NQ - 1) / (64 * NQ);  // query blocks per (batch, head)
         const int j = (int)(blockIdx.x >> 3);
         const int unit = (j / wq) * 8 + (int)(blockIdx.x & 7);
         if (unit >= p.n_units) return;
@@ -132,46 +138,48 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
     }
     const int qcol = lane & 15, qg = lane >> 4;
 
-    int q0, n_valid;
+    int q0, n_valid;  // n_valid: valid query rows of this wave counted from q0 (over its NQ tiles)
     if (SPLIT) {
         q0 = 0;
         n_valid = p.q_valid;
     } else {
-        q0 = (qblk * 4 + wave) * 16;
+        q0 = (qblk * 4 + wave) * 16 * NQ;
         n_valid = p.q_rows_per_batch - q0;
         if (n_valid <= 0) return;  // whole wave out of range (no barriers in the non-split kernel)
-        if (n_valid > 16) n_valid = 16;
+        if (n_valid > 16 * NQ) n_valid = 16 * NQ;
     }
     const int64_t qrow0 = (int64_t)b * p.q_rows_per_batch + q0;
 
-    // Q^T as B operand: lane holds Q[q0 + qcol][ks*32 + 8*qg .. +7]
-    half8 qf[2];
+    // Q^T as B operand: lane holds Q[q0 + 16 t + qcol][ks*32 + 8*qg .. +7]
+    half8 qf[NQ][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (qcol < n_valid) {
-            if (SPLIT && p.q_slab) {
-                const int N = p.H * 64;
-                const int col = h * 64 + ks * 32 + 8 * qg;
-                const float* src = p.q_slab + (qrow0 + qcol) * N + col;
-                floatx4 a0 = *reinterpret_cast<const floatx4*>(src), a1 = *reinterpret_cast<const floatx4*>(src + 4);
-                for (int sidx = 1; sidx < p.q_ksplit; ++sidx) {
-                    a0 += *reinterpret_cast<const floatx4*>(src + (int64_t)sidx * p.q_m_pad * N);
-                    a1 += *reinterpret_cast<const floatx4*>(src + (int64_t)sidx * p.q_m_pad * N + 4);
-                }
-                a0 += *reinterpret_cast<const floatx4*>(p.q_bias + col);
-                a1 += *reinterpret_cast<const floatx4*>(p.q_bias + col + 4);
+    for (int t = 0; t < NQ; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = (_Float16)(a0[j] * p.q_scale);
-                    v[4 + j] = (_Float16)(a1[j] * p.q_scale);
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (t * 16 + qcol < n_valid) {
+                if (SPLIT && p.q_slab) {
+                    const int N = p.H * 64;
+                    const int col = h * 64 + ks * 32 + 8 * qg;
+                    const float* src = p.q_slab + (qrow0 + qcol) * N + col;
+                    floatx4 a0 = *reinterpret_cast<const floatx4*>(src), a1 = *reinterpret_cast<const floatx4*>(src + 4);
+                    for (int sidx = 1; sidx < p.q_ksplit; ++sidx) {
+                        a0 += *reinterpret_cast<const floatx4*>(src + (int64_t)sidx * p.q_m_pad * N);
+                        a1 += *reinterpret_cast<const floatx4*>(src + (int64_t)sidx * p.q_m_pad * N + 4);
+                    }
+                    a0 += *reinterpret_cast<const floatx4*>(p.q_bias + col);
+                    a1 += *reinterpret_cast<const floatx4*>(p.q_bias + col + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = (_Float16)(a0[j] * p.q_scale);
+                        v[4 + j] = (_Float16)(a1[j] * p.q_scale);
+                    }
+                } else {
+                    v = *reinterpret_cast<const half8*>(p.q + (qrow0 + t * 16 + qcol) * p.ldq + h * 64 + ks * 32 + 8 * qg);
                 }
-            } else {
-                v = *reinterpret_cast<const half8*>(p.q + (qrow0 + qcol) * p.ldq + h * 64 + ks * 32 + 8 * qg);
             }
+            qf[t][ks] = v;
         }
-        qf[ks] = v;
-    }
 
     const int64_t head_base = ((int64_t)b * p.H + h) * (int64_t)p.Tp * 64;
     const half_t* kbase = p.kp + head_base + lane * 8;
@@ -179,10 +187,15 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
     const int n_blocks = p.Tp / 32;
     const int kb_begin = SPLIT ? wave : 0, kb_step = SPLIT ? XA_WAVES : 1;
 
-    floatx4 o[4];
+    floatx4 o[NQ][4];
+    float m_run[NQ], l_run[NQ];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int t = 0; t < NQ; ++t) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        m_run[t] = -INFINITY;
+        l_run[t] = 0.f;
+    }
 
     half8 kf[4], vf[4];
     if (kb_begin < n_blocks) {
@@ -207,52 +220,59 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
                 vf[i] = kv_load<SPLIT>(vbase + ((int64_t)nxt * 4 + i) * 512);
             }
         }
-        // S^T tiles: rows = keys, cols = queries.  kc[tile*2 + ks]
-        floatx4 s0 = floatx4{0.f, 0.f, 0.f, 0.f}, s1 = floatx4{0.f, 0.f, 0.f, 0.f};
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0], qf[0], s0, 0, 0, 0);
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1], qf[1], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[2], qf[0], s1, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[3], qf[1], s1, 0, 0, 0);
-        float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-        if (kb * 32 + 32 > p.T) {  // tail block: mask padded keys
+        const bool tail = kb * 32 + 32 > p.T;
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            // S^T tiles: rows = keys, cols = queries.  kc[tile*2 + ks]
+            floatx4 s0 = floatx4{0.f, 0.f, 0.f, 0.f}, s1 = floatx4{0.f, 0.f, 0.f, 0.f};
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0], qf[t][0], s0, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1], qf[t][1], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[2], qf[t][0], s1, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[3], qf[t][1], s1, 0, 0, 0);
+            float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            if (tail) {  // tail block: mask padded keys
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = kb * 32 + (j < 4 ? 4 * qg + j : 16 + 4 * qg + (j - 4));
+                    if (key >= p.T) sv[j] = -INFINITY;
+                }
+            }
+            float bm = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+            bm = fmaxf(bm, __shfl_xor(bm, 16));
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float m_new = fmaxf(m_run[t], bm);  // every block holds >= 1 valid key, so m_new is finite
+            const float alpha = __expf(m_run[t] - m_new);
+            float ps = 0.f;
+            half8 pf;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int key = kb * 32 + (j < 4 ? 4 * qg + j : 16 + 4 * qg + (j - 4));
-                if (key >= p.T) sv[j] = -INFINITY;
+                const float e = __expf(sv[j] - m_new);
+                ps += e;
+                pf[j] = (_Float16)e;
             }
-        }
-        float bm = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-        bm = fmaxf(bm, __shfl_xor(bm, 16));
-        bm = fmaxf(bm, __shfl_xor(bm, 32));
-        const float m_new = fmaxf(m_run, bm);  // every block holds >= 1 valid key, so m_new is finite
-        const float alpha = __expf(m_run - m_new);
-        float ps = 0.f;
-        half8 pf;
+            ps += __shfl_xor(ps, 16);
+            ps += __shfl_xor(ps, 32);
+            l_run[t] = l_run[t] * alpha + ps;
+            m_run[t] = m_new;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float e = __expf(sv[j] - m_new);
-            ps += e;
-            pf[j] = (_Float16)e;
-        }
-        ps += __shfl_xor(ps, 16);
-        ps += __shfl_xor(ps, 32);
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            o[dt] *= alpha;
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vc[dt], pf, o[dt], 0, 0, 0);
+            for (int dt = 0; dt < 4; ++dt) {
+                o[t][dt] *= alpha;
+                o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vc[dt], pf, o[t][dt], 0, 0, 0);
+            }
         }
     }
 
     if (!SPLIT) {
-        if (qcol < n_valid) {
-            const float inv = 1.f / l_run;
-            half_t* dst = p.out + (qrow0 + qcol) * p.ldo + h * 64 + 4 * qg;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<half4*>(dst + dt * 16) = half4{(_Float16)(o[dt][0] * inv), (_Float16)(o[dt][1] * inv),
-                                                                 (_Float16)(o[dt][2] * inv), (_Float16)(o[dt][3] * inv)};
+        for (int t = 0; t < NQ; ++t) {
+            if (t * 16 + qcol < n_valid) {
+                const float inv = 1.f / l_run[t];
+                half_t* dst = p.out + (qrow0 + t * 16 + qcol) * p.ldo + h * 64 + 4 * qg;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<half4*>(dst + dt * 16) = half4{(_Float16)(o[t][dt][0] * inv), (_Float16)(o[t][dt][1] * inv),
+                                                                     (_Float16)(o[t][dt][2] * inv), (_Float16)(o[t][dt][3] * inv)};
+            }
         }
         return;
     } else {
@@ -260,13 +280,13 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
         __shared__ float sl[XA_WAVES][16];
         __shared__ float so[XA_WAVES][64][17];
         if (qg == 0) {
-            sm[wave][qcol] = m_run;
-            sl[wave][qcol] = l_run;
+            sm[wave][qcol] = m_run[0];
+            sl[wave][qcol] = l_run[0];
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) so[wave][dt * 16 + 4 * qg + r][qcol] = o[dt][r];
+            for (int r = 0; r < 4; ++r) so[wave][dt * 16 + 4 * qg + r][qcol] = o[0][dt][r];
         __syncthreads();
         // 16 queries x 64 dims = 1024 outputs, 4 consecutive dims per thread (threads 0..255)
         const int qq = tid >> 4, d0 = (tid & 15) * 4;
@@ -301,7 +321,10 @@ void launch_attn_full(const half_t* q, int64_t ldq, const half_t* kp, const half
     WRS_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && T >= 1 && Tq >= 1, "attn_full: bad shape");
     AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, Tq, 0, out, ldo, nullptr, 0, 0, nullptr, 1.f, n_batch * H};
     const int64_t units8 = cdiv((int64_t)n_batch * H, 8);
-    attn_mfma_kernel<false><<<(unsigned)(8 * units8 * cdiv(Tq, 64)), 256, 0, s>>>(p);
+    static const int nq = getenv("WRS_ATTN_NQ") ? atoi(getenv("WRS_ATTN_NQ")) : ENC_ATTN_NQ;
+    if (nq == 4) attn_mfma_kernel<false, 4><<<(unsigned)(8 * units8 * cdiv(Tq, 256)), 256, 0, s>>>(p);
+    else if (nq == 2) attn_mfma_kernel<false, 2><<<(unsigned)(8 * units8 * cdiv(Tq, 128)), 256, 0, s>>>(p);
+    else attn_mfma_kernel<false, 1><<<(unsigned)(8 * units8 * cdiv(Tq, 64)), 256, 0, s>>>(p);
 }
 
 void launch_attn_cross(const float* q_slab, int q_ksplit, int q_m_pad, const float* q_bias, float q_scale, const half_t* kp,
@@ -310,7 +333,7 @@ void launch_attn_cross(const float* q_slab, int q_ksplit, int q_m_pad, const flo
     WRS_REQUIRE(T >= 1 && q_slab && q_bias && q_ksplit >= 1, "attn_cross: bad argument");
     AttnParams p{nullptr, 0, kp, vp, T, (int)round_up(T, 32), H, G, G, out, 0, q_slab, q_ksplit, q_m_pad, q_bias, q_scale, 0};
     dim3 grid(1, (unsigned)H, (unsigned)n_audio);
-    attn_mfma_kernel<true><<<grid, XA_WAVES * 64, 0, s>>>(p);
+    attn_mfma_kernel<true, 1><<<grid, XA_WAVES * 64, 0, s>>>(p);
 }
 
 // ------------------------------------------------------------------------------------------ decode self-attention

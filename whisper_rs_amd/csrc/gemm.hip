@@ -302,163 +302,22 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
     gemm_epilogue(p, acc, (int64_t)m0 + wx * 64, n0 + wy * 64, lane);
 }
 
-// ------------------------------------------------------------------------------------------ ping-pong GEMM
-// 256x128x64 tiles, 8 waves in two groups of four (group g owns rows 128 g .. 128 g + 127, each wave a 64x64 block as
-// above).  Measured on the 4-wave kernel (profiles/r01_gemm_*): a wave spends ~95 cycles of ISSUE per 1-KiB
-// direct-to-LDS piece — 8 pieces cost more than the k-tile's 32 MFMAs — and, being in order, cannot overlap the two;
-// a CU pulls 90 GB/s from L2 with 4 waves issuing and 140 GB/s with 8 (scripts/micro/l2_to_lds_bw.cpp), while that kernel
-// uses 45.  So the two groups alternate roles every half k-tile ("slot"): while one group's 4 waves (one per SIMD) run
-// their 32 MFMAs, the other group's 4 waves read the fragments of their next k-tile from LDS and issue their share of a
-// future tile's loads.  Schedule (t = k-tile, T(u) = loads of tile u, R = 16 fragment reads, M = 32 MFMAs):
-//     slot 2t   : group 0  M_t                         group 1  R_t, issue T(t+2)
-//     slot 2t+1 : group 0  R_(t+1), issue T(t+3)       group 1  M_t
-// with one workgroup barrier per slot and a 3-slot LDS ring (144 KiB): T(u) reuses the slot of T(u-3), which both groups
-// have read by the time it is requested, and is waited for (counted vmcnt, 6 pieces per wave per tile stay in flight)
-// at the end of slot 2u-2, one slot before its first reader.  The weight tile is shared by both groups: 48 KiB of
-// loads per 2 x (128x128x64) of work instead of 64.
-template <bool APACKED>
-__global__ __launch_bounds__(512) void gemm_f16_pp_kernel(const GemmParams p) {
-    constexpr int STAGE = 3072;  // half8 units per ring slot: activations 256 rows x 128 B (2048) + weights 16 fragments (1024)
-    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
-    half8* smem = reinterpret_cast<half8*>(gemm_smem);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int grp = wave >> 2, w4 = wave & 3;
-    // XCD-aware grouped tile order (see gemm_f16_kernel), 256-row tiles
-    const int mt_n = (p.M + 255) >> 8, nt_n = (p.N + 127) >> 7;
-    const int tiles = mt_n * nt_n, per_xcd = (tiles + 7) >> 3;
-    const int seq = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (seq >= tiles) return;  // whole workgroup, before any barrier
-    const int band = seq / (8 * nt_n);
-    const int band_m0 = band * 8;
-    const int band_rows = min(8, mt_n - band_m0);
-    const int r = seq - band * 8 * nt_n;
-    const int m0 = (band_m0 + r % band_rows) * 256, n0 = (r / band_rows) * 128;
-
-    // this wave's share of a tile: activation pieces 4 wave .. 4 wave + 3 (8 rows each: the rows of its own group),
-    // weight pieces 2 wave, 2 wave + 1
-    const half_t* a_ptr[4];
-    const half_t* w_ptr[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int f = wave * 4 + j;
-        if (APACKED) {
-            a_ptr[j] = p.a + ((int64_t)(m0 / 16 + (f >> 1)) * p.ksteps + (f & 1)) * 512 + lane * 8;
-        } else {
-            const int rl = f * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((rl >> 1) & 7);
-            int64_t m = m0 + rl;
-            if (m > p.M - 1) m = p.M - 1;
-            a_ptr[j] = p.a + (m / p.a_rpb) * p.a_bs + (m % p.a_rpb) * p.lda + chunk * 8;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int f = wave * 2 + j;
-        w_ptr[j] = p.wp + ((int64_t)(n0 / 16 + (f >> 1)) * p.ksteps + (f & 1)) * 512 + lane * 8;
-    }
-    const int nk = p.K / 64 / p.ksplit;
-    const int kt0 = blockIdx.y * nk;
-#define WRS_PP_ISSUE(u_)                                                                                                       \
-    do {                                                                                                                       \
-        half8* st_ = smem + ((u_) % 3) * STAGE;                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                          \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[j] + (int64_t)(kt0 + (u_)) * (APACKED ? 1024 : 64)), \
-                                             (__attribute__((address_space(3))) void*)(st_ + (wave * 4 + j) * 64), 16, 0, 0);  \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                          \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[j] + (int64_t)(kt0 + (u_)) * 1024), \
-                                             (__attribute__((address_space(3))) void*)(st_ + 2048 + (wave * 2 + j) * 64), 16, 0, 0); \
-    } while (0)
-
-    floatx4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const int wy = w4 >> 1, wx = w4 & 1;  // n half, 64-row block inside the group's 128 rows
-    half8 wf[2][4], af[2][4];
-    auto read_frags = [&](int u) {
-        const half8* As = smem + (u % 3) * STAGE;
-        const half8* Ws = As + 2048;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wf[ks][i] = Ws[((wy * 4 + i) * 2 + ks) * 64 + lane];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (APACKED) {
-                    af[ks][j] = As[((grp * 8 + wx * 4 + j) * 2 + ks) * 64 + lane];
-                } else {
-                    const int rr = grp * 128 + wx * 64 + j * 16 + (lane & 15);
-                    const int q = (ks * 4 + (lane >> 4)) ^ ((rr >> 1) & 7);
-                    af[ks][j] = As[rr * 8 + q];
-                }
-            }
-        }
-    };
-    auto mfmas = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // Slot boundary: a bare s_barrier.  __syncthreads() would add a workgroup-scope fence, which the compiler lowers to
-    // vmcnt(0) — it would wait for the direct-to-LDS requests just issued and serialise the ring.  What a boundary
-    // needs is waited for explicitly: this wave's fragment reads (lgkmcnt(0): the slot they came from may be requested
-    // again right after) and the counted vmcnt above it.
-#define WRS_PP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    // prologue: tiles 0..2 fill the ring; group 0 takes its first fragments
-    WRS_PP_ISSUE(0);
-    if (nk > 1) WRS_PP_ISSUE(1);
-    if (nk > 2) WRS_PP_ISSUE(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WRS_PP_BARRIER();
-    if (grp == 0) read_frags(0);
-    WRS_PP_BARRIER();
-    if (grp == 0) {
-        for (int t = 0; t < nk; ++t) {
-            mfmas();                                        // slot 2t: M_t
-            // T(t+1) must have landed for everyone before slot 2t+1; this wave's younger request T(t+2) stays in flight
-            if (t >= 1 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            WRS_PP_BARRIER();
-            if (t + 1 < nk) read_frags(t + 1);              // slot 2t+1: R_(t+1), then T(t+3) into the slot of T(t)
-            if (t + 3 < nk) WRS_PP_ISSUE(t + 3);
-            WRS_PP_BARRIER();
-        }
-    } else {
-        for (int t = 0; t < nk; ++t) {
-            read_frags(t);                                  // slot 2t: R_t, then T(t+2) into the slot of T(t-1)
-            if (t >= 1 && t + 2 < nk) {
-                WRS_PP_ISSUE(t + 2);
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            WRS_PP_BARRIER();
-            mfmas();                                        // slot 2t+1: M_t
-            WRS_PP_BARRIER();
-        }
-    }
-#undef WRS_PP_BARRIER
-#undef WRS_PP_ISSUE
-    gemm_epilogue(p, acc, (int64_t)m0 + grp * 128 + wx * 64, n0 + wy * 64, lane);
-}
-
 // ------------------------------------------------------------------------------------------ ping-pong GEMM, 256x256x32
-// Same role alternation as gemm_f16_pp_kernel, sized so that the preparing group is not the bottleneck: what limits
-// that kernel is the ~100 cycles of issue per direct-to-LDS piece (6 pieces + 16 fragment reads per slot against 32
-// MFMAs = 512 cycles).  Here a wave owns a 64x128 block (acc 128 registers) and a k-tile is 32 deep: per slot 4 pieces
-// + 12 fragment reads against the same 32 MFMAs, and half the L2->LDS bytes per flop.  Ring of 4 x 32 KiB.
+// Measured on the 4-wave kernel above (profiles/r01_gemm_*): a wave spends ~95 cycles of ISSUE per 1-KiB direct-to-LDS
+// piece — its 8 pieces per k-tile cost more than the tile's 32 MFMAs — and, being in order, cannot overlap the two; a CU
+// pulls 90 GB/s from L2 with 4 waves issuing and 140 GB/s with 8 (scripts/micro/l2_to_lds_bw.cpp), while that kernel uses
+// 45.  Here 8 waves form two groups of four (group g owns rows 128 g .. 128 g + 127 of a 256x256 tile, each wave a
+// 64x128 block, acc 128 registers) that alternate roles every half k-tile ("slot"): while one group's 4 waves (one per
+// SIMD) run their 32 MFMAs, the other group's read the fragments of their next k-tile from LDS and issue their share of a
+// future tile's loads: 4 pieces + 12 fragment reads per slot against 32 MFMAs, half the L2->LDS bytes per flop of a
+// 128x128 tile.  (A 256x128x64 version — 6 pieces + 16 reads per slot — only matched the 4-wave kernel:
+// profiles/r01_gemm_pingpong_256x128.log.)  Ring of 4 x 32 KiB; T(u) = loads of k-tile u, R = fragment reads, M = MFMAs:
 //     slot 2t   : group 0  M_t                          group 1  R_t, issue T(t+3)
 //     slot 2t+1 : group 0  R_(t+1), issue T(t+4)        group 1  M_t
+// T(u) reuses the ring slot of T(u-4), which both groups have read by then, and is waited for (counted vmcnt: 4 pieces per
+// wave per tile, the younger tiles stay in flight) at the end of slot 2u-2, one slot before its first reader.  Slot
+// boundaries are bare `s_waitcnt lgkmcnt(0); s_barrier`: __syncthreads() carries a workgroup-scope fence that the compiler
+// lowers to vmcnt(0), which would wait for the requests just issued and serialise the ring.
 // Activation tile: 256 rows x 64 B; a piece is 16 rows x 64 B (lane -> row l/4, chunk l%4).  Fragment reads take chunk
 // l>>4 of rows l&15: the chunk position is XOR-swizzled with (row >> 2) & 3 (on the source address of the request, the
 // LDS destination of a direct-to-LDS load being lane-linear) so the 16 lanes of a read group hit 64 distinct banks.
@@ -574,7 +433,6 @@ __global__ __launch_bounds__(512) void gemm_f16_pp2_kernel(const GemmParams p) {
     gemm_epilogue(p, acc1, mrow, n0 + wy * 128 + 64, lane);
 }
 
-static int gemm_pp_min_wgs = 1 << 30;  // the 256x128 variant is no faster than the 4-wave kernel (profiles/r01_gemm_pingpong.log): opt-in
 static int gemm_pp2_min_wgs = 256;
 
 void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t N, int64_t K, const GemmEpi& e,
@@ -605,23 +463,6 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
         static bool attr = false;
         if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); attr = true; }
         gemm_f16_pp2_kernel<<<g, 512, shmem, s>>>(p);
-        return;
-    }
-    // ping-pong kernel (256x128 tiles, one 8-wave workgroup per CU) once its grid fills the chip
-    static const int pp_mode = getenv("WRS_GEMM_PP") ? atoi(getenv("WRS_GEMM_PP")) : 1;  // 0 off, 1 auto, 2 always
-    const int64_t pp_tiles = cdiv(M, 256) * cdiv(N, 128);
-    const bool packed_ok = !A.packed || A.packed_rows >= round_up(M, 256);
-    if (packed_ok && (pp_mode == 2 || (pp_mode == 1 && pp_tiles * p.ksplit >= gemm_pp_min_wgs))) {
-        const dim3 g((unsigned)(8 * cdiv(pp_tiles, 8)), (unsigned)p.ksplit);
-        const size_t shmem = 3 * 3072 * 16;
-        static bool attr[2] = {false, false};
-        if (A.packed) {
-            if (!attr[1]) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); attr[1] = true; }
-            gemm_f16_pp_kernel<true><<<g, 512, shmem, s>>>(p);
-        } else {
-            if (!attr[0]) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); attr[0] = true; }
-            gemm_f16_pp_kernel<false><<<g, 512, shmem, s>>>(p);
-        }
         return;
     }
     const dim3 grid((unsigned)(8 * cdiv(tiles, 8)), (unsigned)p.ksplit);
