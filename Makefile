@@ -4,7 +4,7 @@ ARCH ?= gfx950
 CSRC := whisper_rs_amd/csrc
 OBJDIR := build/obj
 SRCS := $(CSRC)/common.cpp $(CSRC)/gemm.hip $(CSRC)/elementwise.hip $(CSRC)/attention.hip $(CSRC)/logits.hip \
-        $(CSRC)/mel.cpp $(CSRC)/audio_io.cpp $(CSRC)/tokenizer.cpp $(CSRC)/model.cpp $(CSRC)/weights_io.cpp $(CSRC)/decode.cpp $(CSRC)/transcribe.cpp $(CSRC)/capi.cpp
+        $(CSRC)/mel.cpp $(CSRC)/audio_io.cpp $(CSRC)/tokenizer.cpp $(CSRC)/model.cpp $(CSRC)/weights_io.cpp $(CSRC)/decode.cpp $(CSRC)/transcribe.cpp $(CSRC)/pool.cpp $(CSRC)/capi.cpp
 OBJS := $(patsubst $(CSRC)/%,$(OBJDIR)/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) include/wrs.h
 CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-unused-variable

@@ -274,6 +274,24 @@ int wrs_filter_topk(wrs_decode_task* t, const float* logits, const int64_t* toke
                     int32_t n_tokens, int32_t sample_begin, int32_t k, float* out_logprobs, int32_t* out_ids,
                     float* out_filtered);
 
+/* ---------------------------------------------------------------- window pool (multi-GPU / multi-replica work queue) */
+
+/* Fixed-stride 30-s windows are independent units (decode/mod.rs:291-418 has no cross-audio term; the reference itself
+ * transcribes them one after the other, transcribe.rs:151-234): they shard over GPUs with no collective.  A pool runs
+ * one worker thread + one decode task per model replica — replicas on different GPUs of the node (create one model per
+ * device with wrs_model_create(dims, device_id, ..)), or several replicas on one GPU — and hands out batches of
+ * opt->max_audio consecutive windows from a shared queue; every worker keeps its GPU busy in overlapped mode.
+ *   audio: [n_windows, 480000] f32 HOST; result->outputs[w] belongs to window w (same content as
+ *   wrs_decode_task_run_audio on that window); release with wrs_decode_result_free.  The models must outlive the pool and
+ *   must not be used elsewhere while a run is in progress. */
+typedef struct wrs_window_pool wrs_window_pool;
+int wrs_window_pool_create(wrs_model* const* models, int32_t n_models, const wrs_token_ids* ids, const wrs_decode_options* opt,
+                           wrs_window_pool** out);
+/* attach a tokenizer to every worker (outputs then carry `text`); non-owning, NULL detaches */
+int wrs_window_pool_set_tokenizer(wrs_window_pool* p, const wrs_tokenizer* tok);
+int wrs_window_pool_run_audio(wrs_window_pool* p, const float* audio, int64_t n_windows, wrs_decode_result* result);
+void wrs_window_pool_destroy(wrs_window_pool* p);
+
 /* ---------------------------------------------------------------- transcribe (src/transcribe.rs) */
 
 /* reference `TranscribePrompt` (transcribe.rs:25-29); Text(String) is tokenized by the caller */

@@ -268,3 +268,33 @@ def test_overlapped_mode_equals_sequential(gpu):
     again = task.run_audio(batches[2])
     np.testing.assert_array_equal(again[0].tokens, want[2][0].tokens)
     task.close()
+
+
+def test_window_pool_equals_sequential(gpu):
+    """wrs_window_pool_*: worker threads (one per model replica) pulling window batches from a shared queue return, in
+    window order, exactly what a single task returns for each window batch (uneven last batch included)."""
+    from whisper_rs_amd import synth
+    import helpers
+    audio = synth.make_audio(7, seed=900)
+    opts = gpu.DecodeOptions(sample_len=12, max_audio=2)
+    gm = gpu_model(gpu, "micro")
+    task = gpu.DecodeTask(gm, TokenIds.english(), opts)
+    want = []
+    for i in range(0, 7, 2):
+        want += task.run_audio(audio[i:i + 2])
+    task.close()
+    replicas = [gpu.Whisper(MODEL_DIMS["micro"], helpers.weights("micro")) for _ in range(3)]
+    pool = gpu.WindowPool(replicas, TokenIds.english(), opts)
+    for _ in range(2):  # a pool is reusable
+        got = pool.run_audio(audio)
+        assert len(got) == 7
+        for w, g in zip(want, got):
+            np.testing.assert_array_equal(w.tokens, g.tokens)
+            assert w.sum_logprob == g.sum_logprob and w.no_speech_prob == g.no_speech_prob
+    one = pool.run_audio(audio[:1])  # fewer batches than workers: the idle workers just return
+    assert len(one) == 1 and len(one[0].tokens) > 0
+    with pytest.raises(gpu.WrsError):
+        gpu.WindowPool([replicas[0], replicas[0]], TokenIds.english(), opts)
+    pool.close()
+    for r in replicas:
+        r.close()

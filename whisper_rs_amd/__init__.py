@@ -6,7 +6,7 @@ fails loudly (ImportError / WrsError) if it is missing or no gfx950 device is pr
 """
 from .consts import (SAMPLE_RATE, N_FFT, N_MELS, HOP_LENGTH, CHUNK_LENGTH, N_SAMPLES, N_FRAMES, ModelDims, MODEL_DIMS,
                      TokenIds, NON_SPEECH_TOKENS)
-from .api import (audio, Whisper, Tokenizer, TokenExtractMode, DecodeOptions, DecodeOutput, DecodeTask, TranscribePrompt,
+from .api import (audio, Whisper, Tokenizer, TokenExtractMode, DecodeOptions, DecodeOutput, DecodeTask, WindowPool, TranscribePrompt,
                   TranscribeOptions, TranscribeOutput, TranscribeOutputSegment, TranscribeTask, device_count)
 from ._lib import WrsError, load as load_library
 

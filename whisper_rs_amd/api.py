@@ -513,6 +513,50 @@ class DecodeTask:
             pass
 
 
+class WindowPool:
+    """Work queue over independent 30-s windows (include/wrs.h, window pool): one worker per model replica — replicas on
+    different GPUs, or several on one GPU — batches of `options.max_audio` windows, no collective."""
+
+    def __init__(self, models: Sequence[Whisper], tokenizer_ids: TokenIds, options: DecodeOptions):
+        self._lib = L.load()
+        self.models = list(models)
+        self._keep = []
+        c = _fill_decode_options(options, self._keep)
+        ids = _ids_c(tokenizer_ids)
+        arr = (C.c_void_p * len(self.models))(*[m._h for m in self.models])
+        self._h = C.c_void_p()
+        L.check(self._lib.wrs_window_pool_create(arr, len(self.models), C.byref(ids), C.byref(c), C.byref(self._h)))
+
+    def set_tokenizer(self, tokenizer: Optional["Tokenizer"]):
+        self._tokenizer = tokenizer
+        L.check(self._lib.wrs_window_pool_set_tokenizer(self._h, tokenizer._h if tokenizer else None))
+
+    def run_audio(self, audio_: np.ndarray) -> List[DecodeOutput]:
+        a = _f32(audio_)
+        assert a.ndim == 2 and a.shape[1] == N_SAMPLES
+        res = L.DecodeResultC()
+        L.check(self._lib.wrs_window_pool_run_audio(self._h, _ptr(a), a.shape[0], C.byref(res)))
+        self.n_steps = res.n_steps
+        outs = []
+        for i in range(res.n_outputs):
+            o = res.outputs[i]
+            toks = np.ctypeslib.as_array(o.tokens, shape=(o.n_tokens,)).copy() if o.n_tokens > 0 else np.zeros(0, np.int64)
+            outs.append(DecodeOutput(toks, o.avg_logprob, o.no_speech_prob, o.sum_logprob, o.audio_features_device or 0, _take_text(o.text)))
+        self._lib.wrs_decode_result_free(C.byref(res))
+        return outs
+
+    def close(self):
+        if self._h:
+            self._lib.wrs_window_pool_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------------- transcribe
 @dataclass
 class TranscribePrompt:

@@ -1,16 +1,12 @@
 // extern "C" surface of libwrs_mi355x.so — see include/wrs.h for the reference interface each
 // entry replaces.  No exceptions cross this boundary; no torch types appear in it.
-#include "transcribe.h"
+#include "handles.h"
 #include "audio_io.h"
 #include <map>
 #include <mutex>
 #include <fstream>
 #include <sstream>
 
-struct wrs_model { wrs::Model m; };
-struct wrs_decode_task { wrs::DecodeTask t; };
-struct wrs_transcribe_task { wrs::TranscribeTask t; };
-struct wrs_tokenizer { wrs::Tokenizer t; };
 
 namespace wrs {
 const std::string& last_error();

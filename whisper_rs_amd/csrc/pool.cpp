@@ -1,0 +1,127 @@
+// Work queue over independent 30-s windows: the reference transcribes one window after the
+// other on one device; windows cut at a fixed stride are independent units (decode/mod.rs:291-418 has no cross-audio
+// term), so they shard over GPUs with no collective.  A pool owns one worker thread + one DecodeTask per model replica
+// (replicas on different GPUs of the node, or several on one GPU); workers pull batches of up to `batch` consecutive
+// windows from a shared counter and decode them in overlapped mode (the next batch's encoder is queued on the task's
+// side stream before the current one is decoded).  Outputs are returned in window order.
+#include "handles.h"
+#include <atomic>
+#include <mutex>
+#include <thread>
+
+namespace wrs {
+
+struct WindowPool {
+    std::vector<std::unique_ptr<DecodeTask>> tasks;
+    int batch = 1;
+
+    void run_audio(const float* audio, int64_t n_windows, wrs_decode_result* result) {
+        WRS_REQUIRE(audio && result && n_windows >= 1, "window pool: bad argument");
+        memset(result, 0, sizeof(*result));
+        result->outputs = (wrs_decode_output*)calloc((size_t)n_windows, sizeof(wrs_decode_output));
+        result->n_outputs = (int32_t)n_windows;
+        const int64_t n_batches = cdiv(n_windows, batch);
+        std::atomic<int64_t> next{0};
+        std::mutex err_mutex;
+        std::string err;
+        int err_code = 0;
+        std::atomic<int> max_steps{0};
+        auto worker = [&](DecodeTask* t) {
+            try {
+                t->m->use();
+                auto span = [&](int64_t b, const float*& p, int& n) {
+                    p = audio + b * batch * (int64_t)WRS_N_SAMPLES;
+                    n = (int)std::min<int64_t>(batch, n_windows - b * batch);
+                };
+                int64_t cur = next.fetch_add(1);
+                if (cur >= n_batches) return;
+                const float* p; int n;
+                span(cur, p, n);
+                t->encode_async(p, n, WRS_MEM_HOST);
+                while (cur < n_batches) {
+                    const int64_t nxt = next.fetch_add(1);
+                    if (nxt < n_batches) {
+                        span(nxt, p, n);
+                        t->encode_async(p, n, WRS_MEM_HOST);
+                    }
+                    wrs_decode_result r;
+                    t->run_pending(&r);
+                    // hand the outputs over (the per-output buffers change owner; the array of this batch is dropped)
+                    for (int i = 0; i < r.n_outputs; ++i) result->outputs[cur * batch + i] = r.outputs[i];
+                    free(r.outputs);
+                    int ms = max_steps.load();
+                    while (r.n_steps > ms && !max_steps.compare_exchange_weak(ms, r.n_steps)) {}
+                    cur = nxt;
+                }
+            } catch (const Error& e) {
+                std::lock_guard<std::mutex> g(err_mutex);
+                if (err.empty()) { err = e.what(); err_code = e.code; }
+                next.store(n_batches);  // stop handing out work
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> g(err_mutex);
+                if (err.empty()) { err = e.what(); err_code = WRS_EINVAL; }
+                next.store(n_batches);
+            }
+        };
+        std::vector<std::thread> threads;
+        for (auto& t : tasks) threads.emplace_back(worker, t.get());
+        for (auto& th : threads) th.join();
+        // a failed worker may leave queued batches behind: drain them so the tasks stay usable
+        for (auto& t : tasks) {
+            while (!t->pending.empty()) {
+                try {
+                    t->m->use();
+                    wrs_decode_result r;
+                    t->run_pending(&r);
+                    free_decode_result(&r);
+                } catch (...) { t->pending.clear(); }
+            }
+        }
+        result->n_steps = max_steps.load();
+        if (!err.empty()) {
+            free_decode_result(result);
+            throw Error(err_code, err);
+        }
+    }
+};
+
+}  // namespace wrs
+
+struct wrs_window_pool { wrs::WindowPool p; };
+
+using namespace wrs;
+
+extern "C" {
+
+int wrs_window_pool_create(wrs_model* const* models, int32_t n_models, const wrs_token_ids* ids, const wrs_decode_options* opt,
+                           wrs_window_pool** out) {
+    return guarded([&] {
+        WRS_REQUIRE(models && n_models >= 1 && n_models <= 64 && ids && opt && out, "wrs_window_pool_create: bad argument");
+        std::unique_ptr<wrs_window_pool> h(new wrs_window_pool());
+        h->p.batch = opt->max_audio > 0 ? opt->max_audio : 1;
+        for (int i = 0; i < n_models; ++i) {
+            WRS_REQUIRE(models[i], "wrs_window_pool_create: null model");
+            for (int j = 0; j < i; ++j) WRS_REQUIRE(models[j] != models[i], "wrs_window_pool_create: a model handle may back one worker only (a model owns one stream and one encoder workspace)");
+            std::unique_ptr<DecodeTask> t(new DecodeTask());
+            t->configure(&models[i]->m, *ids, *opt);
+            h->p.tasks.push_back(std::move(t));
+        }
+        *out = h.release();
+    });
+}
+int wrs_window_pool_run_audio(wrs_window_pool* p, const float* audio, int64_t n_windows, wrs_decode_result* result) {
+    return guarded([&] { WRS_REQUIRE(p, "null pool"); p->p.run_audio(audio, n_windows, result); });
+}
+int wrs_window_pool_set_tokenizer(wrs_window_pool* p, const wrs_tokenizer* tok) {
+    return guarded([&] {
+        WRS_REQUIRE(p, "null pool");
+        for (auto& t : p->p.tasks) t->tokenizer = tok ? &tok->t : nullptr;
+    });
+}
+void wrs_window_pool_destroy(wrs_window_pool* p) {
+    if (!p) return;
+    for (auto& t : p->p.tasks) { (void)hipSetDevice(t->m->device); t.reset(); }
+    delete p;
+}
+
+}  // extern "C"
