@@ -1,5 +1,16 @@
 #include "common.h"
+#include <mutex>
 namespace wrs {
+hipStream_t utility_stream() {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    WRS_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> g(mu);
+    if (!streams[dev]) HIP_CHECK(hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking));
+    return streams[dev];
+}
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& m) { g_last_error = m; }
 const std::string& last_error() { return g_last_error; }

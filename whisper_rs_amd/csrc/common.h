@@ -58,6 +58,8 @@ static inline int guarded(F&& f) {
     }
 }
 
+hipStream_t utility_stream();  // a non-blocking stream of the calling thread's current device (created on first use)
+
 // device allocation, zero-initialised (GEMM tiles may over-read into padding: it must be finite)
 struct DevBuf {
     void* p = nullptr;
@@ -76,11 +78,13 @@ struct DevBuf {
         if (n == 0) n = 256;
         n = (n + 255) & ~size_t(255);
         HIP_CHECK(hipMalloc(&p, n));
-        // hipMemset on device memory is asynchronous on the NULL stream, and the library's work streams are
-        // hipStreamNonBlocking (they do not order against it): wait here so that no later copy/kernel on a
-        // work stream can be overwritten by a late-landing zero fill.  Allocation is never on the hot path.
-        HIP_CHECK(hipMemset(p, 0, n));
-        HIP_CHECK(hipDeviceSynchronize());
+        // Zero fill on a utility stream of this device (never the legacy NULL stream: that one orders against other
+        // threads' streams and is refused while any of them captures a graph — window-pool workers allocate while their
+        // neighbours replay/capture decode steps), and wait for it: the library's work streams are non-blocking, so a
+        // late-landing zero fill could otherwise overwrite a later copy/kernel.  Allocation is never on the hot path.
+        hipStream_t us = utility_stream();
+        HIP_CHECK(hipMemsetAsync(p, 0, n, us));
+        HIP_CHECK(hipStreamSynchronize(us));
         bytes = n;
     }
     void ensure(size_t n) {

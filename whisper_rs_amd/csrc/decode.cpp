@@ -132,7 +132,8 @@ void DecodeTask::configure(Model* model, const wrs_token_ids& tid, const wrs_dec
     m->use();
     suppress_dev.alloc(std::max<size_t>(suppress_ids.size(), 1) * 4);
     if (!suppress_ids.empty())
-        HIP_CHECK(hipMemcpy(suppress_dev.p, suppress_ids.data(), suppress_ids.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(suppress_dev.p, suppress_ids.data(), suppress_ids.size() * 4, hipMemcpyHostToDevice, utility_stream()));
+        HIP_CHECK(hipStreamSynchronize(utility_stream()));
     sot_tail.clear();
     audio_lang.clear();
     for (int i = 0; i < o.n_sot_sequence_tail; ++i) {

@@ -194,8 +194,9 @@ void launch_layernorm(const float* x, const float* g, const float* b, int64_t M,
 // decode step: x[m] += bias + sum_s slab[s][m] (fixed order => deterministic), then xn = LN(x).
 // Fuses the split-K reduction of the out-projection / MLP-2 GEMM, the residual add
 // (reference model.rs:302-318) and the next LayerNorm into one pass over [M, D].
-// One 256-thread workgroup per row (the step has only <= 320 rows: parallelism comes from splitting
-// the row, and all ksplit slab loads of a thread are independent and in flight together).
+// One 256-thread workgroup per row: parallelism comes from splitting the row, and all ksplit slab loads of a thread are
+// independent and in flight together.  (A wave-per-row variant — no LDS, no barrier — was measured 2 % slower on the
+// whole decode at 1280 rows.)
 template <int NV>  // float4 vectors per thread: D <= 1024 * NV
 __global__ __launch_bounds__(256) void finish_residual_ln_kernel(float* __restrict__ x, const float* __restrict__ slab,
                                                                  int ksplit, int m_pad, const float* __restrict__ bias,

@@ -46,7 +46,8 @@ static void ensure_tables(MelWorkspace& ws, const float* filter_host_or_null) {
                 tw[(size_t)(2 * b + 1) * 400 + n] = (float)(-win * std::sin(ang));
             }
         ws.twiddle.alloc(tw.size() * 4);
-        HIP_CHECK(hipMemcpy(ws.twiddle.p, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(ws.twiddle.p, tw.data(), tw.size() * 4, hipMemcpyHostToDevice, utility_stream()));
+        HIP_CHECK(hipStreamSynchronize(utility_stream()));
         ws.filter.alloc((size_t)128 * kPowerLd * 4);
         ws.tables_ready = true;
         ws.filter_host.clear();
@@ -58,7 +59,8 @@ static void ensure_tables(MelWorkspace& ws, const float* filter_host_or_null) {
         std::vector<float> padded((size_t)128 * kPowerLd, 0.f);
         for (int i = 0; i < 80; ++i)
             for (int k = 0; k < 201; ++k) padded[(size_t)i * kPowerLd + k] = f[i * 201 + k];
-        HIP_CHECK(hipMemcpy(ws.filter.p, padded.data(), padded.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(ws.filter.p, padded.data(), padded.size() * 4, hipMemcpyHostToDevice, utility_stream()));
+        HIP_CHECK(hipStreamSynchronize(utility_stream()));
         ws.filter_host = f;
     }
 }

@@ -253,7 +253,8 @@ void Model::finalize() {
             }
         DevBuf b;
         b.alloc(tab.size() * 4);
-        HIP_CHECK(hipMemcpy(b.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(b.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, utility_stream()));
+        HIP_CHECK(hipStreamSynchronize(utility_stream()));
         enc_pos = b.as<float>();
         owned.push_back(std::move(b));
     }
