@@ -109,6 +109,45 @@ def whole_job_xrt(steps, batch, world, elapsed):
     return steps * batch * 30.0 * world / elapsed
 
 
+def bench_lanes(args, W, synth, models, ids, dims, dev, rank, world, use_dist):
+    """--lanes L: L model replicas on this GPU behind one window pool (worker thread per replica, overlapped mode each)."""
+    import torch.distributed as dist
+    opts = W.DecodeOptions(sample_len=args.sample_len, max_audio=args.batch, token_extract_mode=W.TokenExtractMode.BeamSearch(args.beam, 1.0))
+    pool = W.WindowPool(models, ids, opts, overlapped=not args.no_overlap)
+    n_win = args.lanes * args.batch
+    audio = torch.from_numpy(synth.make_audio(n_win, seed=window_seed(rank))).to(dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pool.run_audio(audio.data_ptr(), n_win)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pool.run_audio(audio.data_ptr(), n_win)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "xRT (audio-sec/wall-sec), large-v2 beam=5 fp16" if args.model == "large-v2" else f"xRT (audio-sec/wall-sec), {args.model} beam={args.beam} fp16",
+            "value": round(whole_job_xrt(args.steps, n_win, world, elapsed), 2), "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{args.model} beam={args.beam}, {args.lanes} lanes x {args.batch} independent synthetic 30-s windows per GPU per step "
+                                   f"(window pool: one model replica + worker thread per lane), sample_len {args.sample_len}",
+                       "windows_per_step_per_gpu": n_win, "lanes": args.lanes, "beam": args.beam, "sample_len": args.sample_len,
+                       "sharding": f"windows x{world}, no collective"},
+            "roofline": None}), flush=True)
+    pool.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +157,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="30-s windows per step per GPU (independent units; 256 x beam 5 = 1280 decoder rows)")
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--sample-len", type=int, default=224)
+    ap.add_argument("--lanes", type=int, default=1, help="model replicas per GPU, each decoding its own batches from its own worker thread (wrs_window_pool); "
+                    "--batch is then windows per lane and a step is lanes x batch windows.  Not the default: per-launch timing of a kernel "
+                    "is not meaningful while several lanes share the GPU, so no roofline object is reported")
     ap.add_argument("--no-overlap", action="store_true", help="sequential passes: do not queue the next step's mel/encoder/cross-K/V on the side stream while this step decodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-profile", action="store_true", help="extra eager pass with per-kernel HIP-event timing (stderr)")
@@ -140,11 +182,19 @@ def main():
     from whisper_rs_amd import synth
     dims = W.MODEL_DIMS[args.model]
     ids = W.TokenIds.for_vocab(dims.n_vocab)
-    model = W.Whisper(dims, device=local_rank)
-    for name, t in make_weights_device(dims, dev, seed=0).items():
-        model.set_tensor(name, t)
-    model.finalize()
+    weights = make_weights_device(dims, dev, seed=0)
+    models = []
+    for _ in range(max(1, args.lanes)):
+        mdl = W.Whisper(dims, device=local_rank)
+        for name, t in weights.items():
+            mdl.set_tensor(name, t)
+        mdl.finalize()
+        models.append(mdl)
+    model = models[0]
+    del weights
     torch.cuda.empty_cache()
+    if args.lanes > 1:
+        return bench_lanes(args, W, synth, models, ids, dims, dev, rank, world, use_dist)
     task = W.DecodeTask(model, ids, W.DecodeOptions(sample_len=args.sample_len, max_audio=args.batch,
                                                     token_extract_mode=W.TokenExtractMode.BeamSearch(args.beam, 1.0)))
     # synthetic 30-s windows, distinct per rank, resident in HBM before the timed region

@@ -281,15 +281,17 @@ int wrs_filter_topk(wrs_decode_task* t, const float* logits, const int64_t* toke
  * one worker thread + one decode task per model replica — replicas on different GPUs of the node (create one model per
  * device with wrs_model_create(dims, device_id, ..)), or several replicas on one GPU — and hands out batches of
  * opt->max_audio consecutive windows from a shared queue; every worker keeps its GPU busy in overlapped mode.
- *   audio: [n_windows, 480000] f32 HOST; result->outputs[w] belongs to window w (same content as
+ *   audio: [n_windows, 480000] f32, host memory (or device memory when every replica sits on that GPU); result->outputs[w] belongs to window w (same content as
  *   wrs_decode_task_run_audio on that window); release with wrs_decode_result_free.  The models must outlive the pool and
  *   must not be used elsewhere while a run is in progress. */
 typedef struct wrs_window_pool wrs_window_pool;
+/* overlapped != 0: every worker queues its next batch's encoder while it decodes (a second cross-K/V buffer per worker:
+ * 2 x 2 x 1500 x n_text_states x n_text_layers x max_audio bytes more device memory); 0: encoder and decode back to back. */
 int wrs_window_pool_create(wrs_model* const* models, int32_t n_models, const wrs_token_ids* ids, const wrs_decode_options* opt,
-                           wrs_window_pool** out);
+                           int overlapped, wrs_window_pool** out);
 /* attach a tokenizer to every worker (outputs then carry `text`); non-owning, NULL detaches */
 int wrs_window_pool_set_tokenizer(wrs_window_pool* p, const wrs_tokenizer* tok);
-int wrs_window_pool_run_audio(wrs_window_pool* p, const float* audio, int64_t n_windows, wrs_decode_result* result);
+int wrs_window_pool_run_audio(wrs_window_pool* p, const float* audio, int64_t n_windows, int mem_kind, wrs_decode_result* result);
 void wrs_window_pool_destroy(wrs_window_pool* p);
 
 /* ---------------------------------------------------------------- transcribe (src/transcribe.rs) */

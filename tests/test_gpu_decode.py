@@ -284,6 +284,10 @@ def test_window_pool_equals_sequential(gpu):
         want += task.run_audio(audio[i:i + 2])
     task.close()
     replicas = [gpu.Whisper(MODEL_DIMS["micro"], helpers.weights("micro")) for _ in range(3)]
+    seq_pool = gpu.WindowPool(replicas[:2], TokenIds.english(), opts, overlapped=False)
+    for w, g in zip(want, seq_pool.run_audio(audio)):
+        np.testing.assert_array_equal(w.tokens, g.tokens)
+    seq_pool.close()
     pool = gpu.WindowPool(replicas, TokenIds.english(), opts)
     for _ in range(2):  # a pool is reusable
         got = pool.run_audio(audio)

@@ -517,7 +517,7 @@ class WindowPool:
     """Work queue over independent 30-s windows (include/wrs.h, window pool): one worker per model replica — replicas on
     different GPUs, or several on one GPU — batches of `options.max_audio` windows, no collective."""
 
-    def __init__(self, models: Sequence[Whisper], tokenizer_ids: TokenIds, options: DecodeOptions):
+    def __init__(self, models: Sequence[Whisper], tokenizer_ids: TokenIds, options: DecodeOptions, overlapped: bool = True):
         self._lib = L.load()
         self.models = list(models)
         self._keep = []
@@ -525,17 +525,21 @@ class WindowPool:
         ids = _ids_c(tokenizer_ids)
         arr = (C.c_void_p * len(self.models))(*[m._h for m in self.models])
         self._h = C.c_void_p()
-        L.check(self._lib.wrs_window_pool_create(arr, len(self.models), C.byref(ids), C.byref(c), C.byref(self._h)))
+        L.check(self._lib.wrs_window_pool_create(arr, len(self.models), C.byref(ids), C.byref(c), int(overlapped), C.byref(self._h)))
 
     def set_tokenizer(self, tokenizer: Optional["Tokenizer"]):
         self._tokenizer = tokenizer
         L.check(self._lib.wrs_window_pool_set_tokenizer(self._h, tokenizer._h if tokenizer else None))
 
-    def run_audio(self, audio_: np.ndarray) -> List[DecodeOutput]:
-        a = _f32(audio_)
-        assert a.ndim == 2 and a.shape[1] == N_SAMPLES
+    def run_audio(self, audio_, n_windows: Optional[int] = None) -> List[DecodeOutput]:
+        """audio_: numpy [n, 480000] (host), or a device pointer (int) with n_windows when all replicas share that GPU."""
         res = L.DecodeResultC()
-        L.check(self._lib.wrs_window_pool_run_audio(self._h, _ptr(a), a.shape[0], C.byref(res)))
+        if isinstance(audio_, int):
+            L.check(self._lib.wrs_window_pool_run_audio(self._h, C.c_void_p(audio_), n_windows, L.WRS_MEM_DEVICE, C.byref(res)))
+        else:
+            a = _f32(audio_)
+            assert a.ndim == 2 and a.shape[1] == N_SAMPLES
+            L.check(self._lib.wrs_window_pool_run_audio(self._h, _ptr(a), a.shape[0], L.WRS_MEM_HOST, C.byref(res)))
         self.n_steps = res.n_steps
         outs = []
         for i in range(res.n_outputs):

@@ -47,12 +47,15 @@ void DecodeTask::encode_async(const float* audio, int n_audio, int mem_kind) {
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_least));
         for (auto& e : side_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    // the buffer that is neither queued nor (if nothing is queued) the one the last decode read: decode is synchronous
+    // on the host, so no decode step is in flight here and, with nothing queued, the buffer in use is free as well — the
+    // second buffer is only allocated once a batch is queued while another one is pending
+    int buf = pending.empty() ? st.cross_sel : (pending.back().buf ^ 1);
+    if (buf == 1 && st.cross_kp2.bytes == 0) {
         st.cross_kp2.alloc(st.cross_kp.bytes);
         st.cross_vp2.alloc(st.cross_vp.bytes);
     }
-    // the buffer that is neither queued nor (if nothing is queued) the one the last decode read: decode is synchronous
-    // on the host, so no decode step is in flight here
-    const int buf = pending.empty() ? (st.cross_sel ^ 1) : (pending.back().buf ^ 1);
     hipStream_t main_stream = m->stream;
     m->stream = side;  // every launch helper of the model enqueues on m->stream
     try {

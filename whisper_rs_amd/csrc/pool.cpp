@@ -14,9 +14,12 @@ namespace wrs {
 struct WindowPool {
     std::vector<std::unique_ptr<DecodeTask>> tasks;
     int batch = 1;
+    bool overlapped = true;
 
-    void run_audio(const float* audio, int64_t n_windows, wrs_decode_result* result) {
+    void run_audio(const float* audio, int64_t n_windows, int mem_kind, wrs_decode_result* result) {
         WRS_REQUIRE(audio && result && n_windows >= 1, "window pool: bad argument");
+        if (mem_kind == WRS_MEM_DEVICE)
+            for (auto& t : tasks) WRS_REQUIRE(t->m->device == tasks[0]->m->device, "window pool: a device buffer can only feed replicas on its own GPU");
         memset(result, 0, sizeof(*result));
         result->outputs = (wrs_decode_output*)calloc((size_t)n_windows, sizeof(wrs_decode_output));
         result->n_outputs = (int32_t)n_windows;
@@ -36,21 +39,34 @@ struct WindowPool {
                 int64_t cur = next.fetch_add(1);
                 if (cur >= n_batches) return;
                 const float* p; int n;
+                auto deliver = [&](int64_t b, wrs_decode_result& r) {
+                    // hand the outputs over (the per-output buffers change owner; the array of this batch is dropped)
+                    for (int i = 0; i < r.n_outputs; ++i) result->outputs[b * batch + i] = r.outputs[i];
+                    free(r.outputs);
+                    int ms = max_steps.load();
+                    while (r.n_steps > ms && !max_steps.compare_exchange_weak(ms, r.n_steps)) {}
+                };
+                if (!overlapped) {  // one cross-K/V buffer per worker: encoder and decode of a batch back to back
+                    for (; cur < n_batches; cur = next.fetch_add(1)) {
+                        span(cur, p, n);
+                        t->encode_async(p, n, mem_kind);
+                        wrs_decode_result r;
+                        t->run_pending(&r);
+                        deliver(cur, r);
+                    }
+                    return;
+                }
                 span(cur, p, n);
-                t->encode_async(p, n, WRS_MEM_HOST);
+                t->encode_async(p, n, mem_kind);
                 while (cur < n_batches) {
                     const int64_t nxt = next.fetch_add(1);
                     if (nxt < n_batches) {
                         span(nxt, p, n);
-                        t->encode_async(p, n, WRS_MEM_HOST);
+                        t->encode_async(p, n, mem_kind);
                     }
                     wrs_decode_result r;
                     t->run_pending(&r);
-                    // hand the outputs over (the per-output buffers change owner; the array of this batch is dropped)
-                    for (int i = 0; i < r.n_outputs; ++i) result->outputs[cur * batch + i] = r.outputs[i];
-                    free(r.outputs);
-                    int ms = max_steps.load();
-                    while (r.n_steps > ms && !max_steps.compare_exchange_weak(ms, r.n_steps)) {}
+                    deliver(cur, r);
                     cur = nxt;
                 }
             } catch (const Error& e) {
@@ -94,11 +110,12 @@ using namespace wrs;
 extern "C" {
 
 int wrs_window_pool_create(wrs_model* const* models, int32_t n_models, const wrs_token_ids* ids, const wrs_decode_options* opt,
-                           wrs_window_pool** out) {
+                           int overlapped, wrs_window_pool** out) {
     return guarded([&] {
         WRS_REQUIRE(models && n_models >= 1 && n_models <= 64 && ids && opt && out, "wrs_window_pool_create: bad argument");
         std::unique_ptr<wrs_window_pool> h(new wrs_window_pool());
         h->p.batch = opt->max_audio > 0 ? opt->max_audio : 1;
+        h->p.overlapped = overlapped != 0;
         for (int i = 0; i < n_models; ++i) {
             WRS_REQUIRE(models[i], "wrs_window_pool_create: null model");
             for (int j = 0; j < i; ++j) WRS_REQUIRE(models[j] != models[i], "wrs_window_pool_create: a model handle may back one worker only (a model owns one stream and one encoder workspace)");
@@ -109,8 +126,8 @@ int wrs_window_pool_create(wrs_model* const* models, int32_t n_models, const wrs
         *out = h.release();
     });
 }
-int wrs_window_pool_run_audio(wrs_window_pool* p, const float* audio, int64_t n_windows, wrs_decode_result* result) {
-    return guarded([&] { WRS_REQUIRE(p, "null pool"); p->p.run_audio(audio, n_windows, result); });
+int wrs_window_pool_run_audio(wrs_window_pool* p, const float* audio, int64_t n_windows, int mem_kind, wrs_decode_result* result) {
+    return guarded([&] { WRS_REQUIRE(p, "null pool"); p->p.run_audio(audio, n_windows, mem_kind, result); });
 }
 int wrs_window_pool_set_tokenizer(wrs_window_pool* p, const wrs_tokenizer* tok) {
     return guarded([&] {
