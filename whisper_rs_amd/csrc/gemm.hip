@@ -311,7 +311,9 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
 // SIMD) run their 32 MFMAs, the other group's read the fragments of their next k-tile from LDS and issue their share of a
 // future tile's loads: 4 pieces + 12 fragment reads per slot against 32 MFMAs, half the L2->LDS bytes per flop of a
 // 128x128 tile.  (A 256x128x64 version — 6 pieces + 16 reads per slot — only matched the 4-wave kernel:
-// profiles/r01_gemm_pingpong_256x128.log.)  Ring of 4 x 32 KiB; T(u) = loads of k-tile u, R = fragment reads, M = MFMAs:
+// profiles/r01_gemm_pingpong_256x128.log; a 128x256x32 packed-activation version for the decode-step shapes, M = 1280,
+// is 1.4x more efficient per CU but leaves 40 % of the CUs without a tile and loses 10-18 % to the 4-wave kernel:
+// profiles/r01_gemm_pingpong_128x256_decode.log.)  Ring of 4 x 32 KiB; T(u) = loads of k-tile u, R = fragment reads, M = MFMAs:
 //     slot 2t   : group 0  M_t                          group 1  R_t, issue T(t+3)
 //     slot 2t+1 : group 0  R_(t+1), issue T(t+4)        group 1  M_t
 // T(u) reuses the ring slot of T(u-4), which both groups have read by then, and is waited for (counted vmcnt: 4 pieces per
