@@ -91,3 +91,29 @@ def test_transcribe_segment_slicing(monkeypatch):
     assert (s1.seek, s1.start_token, s1.end_token) == (200, 0, 2) and abs(s1.start_time - 2.0) < 1e-9 and abs(s1.end_time - 32.0) < 1e-9
     assert out.tokens.tolist() == [ts, 11, 12, ts + 100, ts + 100, ts, 14]
     assert t.decode_task.prompts == [[], [ts, 11, 12, ts + 100, ts + 100]]  # conditioning on previous text (:155-158)
+
+
+def test_oracle_sot_sequence_tail_and_languages():
+    """oracle side of BASELINE config 4 (beyond the reference: OpenAI's [sot, lang, task] prompt and per-window language
+    tokens): prompt layout, language override and detection are self-consistent on a multilingual-vocabulary model."""
+    import torch
+    from helpers import oracle_model, oracle_ids, oracle_decode_options, mel_windows
+    from whisper_rs_amd.consts import MODEL_DIMS, TokenIds
+    from oracle import decode as OD
+    ids = TokenIds.multilingual()
+    oids = oracle_ids(MODEL_DIMS["micro.ml"].n_vocab)
+    first = ids.sot + 1
+    p = OD.DecodePrompt(torch.tensor([7, 8]), oids, (first + 3, ids.transcribe))
+    assert p.initial_tokens.tolist() == [ids.startofprev, 7, 8, ids.sot, first + 3, ids.transcribe]
+    assert p.sample_begin == 6 and p.sot_idx == 3
+    om = oracle_model("micro.ml")
+    mel = torch.from_numpy(mel_windows(2))
+    task = OD.DecodeTask(om, oids, oracle_decode_options(sample_len=5, beam_size=2, sot_sequence_tail=(first, ids.transcribe)))
+    lang, probs = task.detect_language(mel, first, 99)
+    assert probs.shape == (2, 99) and torch.allclose(probs.sum(-1), torch.ones(2), atol=1e-5)
+    assert all(first <= int(x) < first + 99 for x in lang) and torch.equal(lang - first, probs.argmax(-1))
+    base = task.run_batch(mel)
+    task.languages = [first + 10, first]      # window 0 switches language, window 1 keeps the default of the tail
+    other = task.run_batch(mel)
+    assert torch.equal(base[1].tokens, other[1].tokens) and abs(base[1].sum_logprob - other[1].sum_logprob) < 1e-5
+    assert not (torch.equal(base[0].tokens, other[0].tokens) and base[0].sum_logprob == other[0].sum_logprob)
