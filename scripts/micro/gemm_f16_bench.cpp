@@ -17,6 +17,10 @@ int main(int argc, char** argv) {
     struct Shape { const char* name; int N, K; bool f32out, res, gelu; int ksplit; };
     std::vector<Shape> shapes;
     if (dec) {
+        if (getenv("FIXED_COST")) {  // fixed cost of a launch: K = 64 .. 1280 at N = D (100 workgroups) and N = 4D (400)
+            for (int k : {64, 128, 320, 640, 1280}) shapes.push_back({"d_k", D, k, true, false, false, 1});
+            for (int k : {64, 128, 320, 640, 1280}) shapes.push_back({"d_k4", 4 * D, k, true, false, false, 1});
+        }
         for (int ks : {1, 2, 4}) shapes.push_back({"d_DxD", D, D, true, false, false, ks});
         shapes.push_back({"d_qkv", 3 * D, D, true, false, false, 1});
         shapes.push_back({"d_mlp1", 4 * D, D, false, false, true, 1});

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void finish_act_kernel(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float x = a[r];
-            if (act) x = 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+            if (act) x = gelu_exact(x);
             y[r] = (_Float16)x;
         }
         *reinterpret_cast<half4*>(out + pa_off(m, n, N >> 5)) = y;

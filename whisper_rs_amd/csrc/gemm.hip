@@ -23,8 +23,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-
 // ------------------------------------------------------------------------------------------ packing
 size_t packed_weight_halfs(int64_t n_pad, int64_t k_pad) { return (size_t)n_pad * (size_t)k_pad; }
 

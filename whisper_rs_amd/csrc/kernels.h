@@ -6,6 +6,22 @@
 
 namespace wrs {
 
+#ifdef __HIPCC__
+// erf-based GELU (reference model.rs:225-232, `gelu("none")`).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
+// fp32 round-off level; the result is stored as fp16): a third of the instructions of libm's erff, which cost the MLP-1
+// epilogue more than its k-loop at decode-step sizes (64 values per lane).
+__device__ __forceinline__ float gelu_exact(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(t, poly, 1.421413741f);
+    poly = fmaf(t, poly, -0.284496736f);
+    poly = fmaf(t, poly, 0.254829592f);
+    const float erfz = 1.f - poly * t * __expf(-z * z);  // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.f + copysignf(erfz, x));
+}
+#endif
+
 // per-step scalars that live in device memory so that one captured hipGraph serves every step
 struct StepParams {
     int cache_pos;       // self-attention K/V slot written by this step (= tokens so far - 1)
