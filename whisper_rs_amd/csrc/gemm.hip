@@ -297,6 +297,17 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
     }
 #undef WRS_STAGE
 
+#ifdef WRS_EXP_NOSTORE  // micro-benchmark hook (scripts/micro): leave out the epilogue to price it
+    {
+        float sink = 0.f;  // keeps every accumulator (and so every MFMA) alive
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sink += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        if (sink == 12345.678f) reinterpret_cast<float*>(p.c)[0] = 1.f;
+        return;
+    }
+#endif
     gemm_epilogue(p, acc, (int64_t)m0 + wx * 64, n0 + wy * 64, lane);
 }
 
