@@ -137,7 +137,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
             const int64_t m = mrow0 + j * 16 + (lane & 15);
             const bool mok = m < p.M;
             const int64_t mc = mok ? m : p.M - 1;
-            const int64_t mb = mc / p.c_rpb, mr = mc % p.c_rpb;
+            // rows are batched only for the conv outputs; elsewhere c_rpb is "infinite" and the 64-bit division and modulo
+            // (software routines of a few hundred cycles each, 8 per lane per tile) are skipped
+            const bool batched = p.c_rpb <= (int64_t)p.M;
+            const int64_t mb = batched ? mc / p.c_rpb : 0, mr = batched ? mc % p.c_rpb : mc;
             const int64_t crow = mb * p.c_brows + mr + p.c_roff;
             floatx4 pos4[4], res4[4];
 #pragma unroll
@@ -170,7 +173,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
     for (int j = 0; j < 4; ++j) {
         const int64_t m = mrow0 + j * 16 + (lane & 15);
         if (m >= p.M) continue;
-        const int64_t mb = m / p.c_rpb, mr = m % p.c_rpb;
+        const bool batched = p.c_rpb <= (int64_t)p.M;
+        const int64_t mb = batched ? m / p.c_rpb : 0, mr = batched ? m % p.c_rpb : m;
         const int64_t crow = mb * p.c_brows + mr + p.c_roff;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -308,6 +312,30 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
         return;
     }
 #endif
+    // Split-K slabs of full tiles: transpose the 128x128 fp32 tile through LDS (the operand ring is free now) so that every
+    // store instruction writes two whole 512-byte rows instead of 16 separate 64-byte pieces.
+    if (p.ksplit > 1 && m0 + 128 <= p.M && n0 + 128 <= p.N && (p.ldc & 3) == 0) {
+        float* tile = reinterpret_cast<float*>(&lds[0][0][0][0]);  // [128][128] fp32 = 64 KiB
+        // chunk swizzle: 16-byte chunk c of row r is kept at chunk c ^ (r & 7) (writes and reads spread over the banks)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int r = wx * 64 + jj * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = (wy * 64 + i * 16 + 4 * (lane >> 4)) >> 2;  // 16-byte chunk index within the row (0..31)
+                *reinterpret_cast<floatx4*>(tile + r * 128 + ((c ^ (r & 7)) << 2)) = acc[i][jj];
+            }
+        }
+        __syncthreads();
+        float* slab = reinterpret_cast<float*>(p.c) + (int64_t)blockIdx.y * p.slab_stride;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int r = wave * 32 + t * 2 + (lane >> 5), c = lane & 31;
+            const floatx4 v = *reinterpret_cast<const floatx4*>(tile + r * 128 + ((c ^ (r & 7)) << 2));
+            *reinterpret_cast<floatx4*>(slab + (int64_t)(m0 + r) * p.ldc + n0 + (c << 2)) = v;
+        }
+        return;
+    }
     gemm_epilogue(p, acc, (int64_t)m0 + wx * 64, n0 + wy * 64, lane);
 }
 
@@ -357,7 +385,8 @@ __global__ __launch_bounds__(512) void gemm_f16_pp2_kernel(const GemmParams p) {
         const int chunk = (lane & 3) ^ ((rl >> 2) & 3);   // global 16-B chunk stored at LDS chunk (lane & 3)
         int64_t m = m0 + rl;
         if (m > p.M - 1) m = p.M - 1;
-        a_ptr[j] = p.a + (m / p.a_rpb) * p.a_bs + (m % p.a_rpb) * p.lda + chunk * 8;
+        a_ptr[j] = (p.a_rpb <= (int64_t)p.M) ? p.a + (m / p.a_rpb) * p.a_bs + (m % p.a_rpb) * p.lda + chunk * 8
+                                             : p.a + m * p.lda + chunk * 8;
         w_ptr[j] = p.wp + ((int64_t)(n0 / 16 + f) * p.ksteps) * 512 + lane * 8;
     }
     const int nk = p.K / 32 / p.ksplit;
