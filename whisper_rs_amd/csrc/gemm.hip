@@ -339,6 +339,128 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
     gemm_epilogue(p, acc, (int64_t)m0 + wx * 64, n0 + wy * 64, lane);
 }
 
+// ------------------------------------------------------------------------------------------ ring GEMM (decode-step shapes)
+// 128x128x64 tiles with SEPARATE loader and MFMA waves: 4 consumer waves (64x64 each, as in gemm_f16_kernel) + 8 loader waves
+// that do nothing but issue direct-to-LDS requests (4 of a k-tile's 32 pieces each).  The N = D GEMMs of a decode step
+// (M = rows <= 1280, packed activations) have 100 tiles, 200 workgroups with split-K 2: a CU never holds two of them and
+// the 4-wave kernel's in-order waves pay request issue (~95 cycles per piece) and MFMA time back to back, 0.55 us per
+// k-tile against 0.23 us of MFMA.  Here the requests of tile t+2 are issued while tile t is multiplied (measured 0.35 us per
+// k-tile, loader-bound); 3-slot LDS ring (96 KiB), one workgroup barrier per k-tile.  Used when the grid has at most one
+// workgroup per CU (a 12-wave, 96-KiB workgroup fills a CU; with more tiles the 4-wave kernel's two workgroups per CU win;
+// a 128x256 variant for the N = 3D / 4D shapes spilled and lost: profiles/r01_gemm_ring_decode.log).
+__global__ __launch_bounds__(768) void gemm_f16_ring_kernel(const GemmParams p) {
+    constexpr int STAGE = 2048;  // half8 units per ring slot: 16 activation + 16 weight fragments
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+    half8* smem = reinterpret_cast<half8*>(gemm_smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int mt_n = (p.M + 127) >> 7, nt_n = (p.N + 127) >> 7;
+    const int tiles = mt_n * nt_n, per_xcd = (tiles + 7) >> 3;
+    const int seq = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (seq >= tiles) return;  // whole workgroup, before any barrier
+    const int band = seq / (8 * nt_n);
+    const int band_m0 = band * 8;
+    const int band_rows = min(8, mt_n - band_m0);
+    const int r = seq - band * 8 * nt_n;
+    const int m0 = (band_m0 + r % band_rows) * 128, n0 = (r / band_rows) * 128;
+    const int nk = p.K / 64 / p.ksplit;
+    const int kt0 = blockIdx.y * nk;
+#define WRS_RING_BARRIER() asm volatile("s_barrier" ::: "memory")
+    floatx4 acc[4][4];
+    const int wy = (wave & 3) >> 1, wx = wave & 1;
+    if (wave >= 4) {
+        // ---------------- loader waves
+        const int lw = wave - 4;
+        const half_t* a_ptr[2];
+        const half_t* w_ptr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int f = lw * 2 + j;  // fragment 0..15: (tile of 16 rows/columns f>>1, k-step f&1)
+            a_ptr[j] = p.a + ((int64_t)(m0 / 16 + (f >> 1)) * p.ksteps + (f & 1)) * 512 + lane * 8;
+            w_ptr[j] = p.wp + ((int64_t)(n0 / 16 + (f >> 1)) * p.ksteps + (f & 1)) * 512 + lane * 8;
+        }
+        auto issue = [&](int u) {
+            half8* st_ = smem + (u % 3) * STAGE;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[j] + (int64_t)(kt0 + u) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(st_ + (lw * 2 + j) * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[j] + (int64_t)(kt0 + u) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(st_ + 1024 + (lw * 2 + j) * 64), 16, 0, 0);
+            }
+        };
+        issue(0);
+        if (nk > 1) issue(1);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WRS_RING_BARRIER();  // tile 0 has landed
+        for (int t = 0; t < nk; ++t) {
+            // slot of tile t+2 = slot of tile t-1, which the consumers left at the previous barrier
+            if (t + 2 < nk) {
+                issue(t + 2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile t+1 landed, tile t+2 in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            WRS_RING_BARRIER();
+        }
+    } else {
+        // ---------------- consumer waves
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        WRS_RING_BARRIER();
+        for (int t = 0; t < nk; ++t) {
+            const half8* As = smem + (t % 3) * STAGE;
+            const half8* Ws = As + 1024;
+            half8 wf[2][4], af[2][4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[ks][i] = Ws[((wy * 4 + i) * 2 + ks) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[ks][j] = As[((wx * 4 + j) * 2 + ks) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            WRS_RING_BARRIER();
+        }
+    }
+    // every wave is past the last barrier of the loop: the ring is free
+    if (p.ksplit > 1 && m0 + 128 <= p.M && n0 + 128 <= p.N && (p.ldc & 3) == 0) {
+        // split-K slab of a full tile: transposed through LDS, stored as whole 512-byte rows by all 12 waves
+        float* tile = reinterpret_cast<float*>(smem);  // [128][128] fp32 = 64 KiB
+        if (wave < 4) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int rr = wx * 64 + jj * 16 + (lane & 15);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = (wy * 64 + i * 16 + 4 * (lane >> 4)) >> 2;
+                    *reinterpret_cast<floatx4*>(tile + rr * 128 + ((c ^ (rr & 7)) << 2)) = acc[i][jj];
+                }
+            }
+        }
+        __syncthreads();
+        float* slab = reinterpret_cast<float*>(p.c) + (int64_t)blockIdx.y * p.slab_stride;
+        for (int t = wave; t < 64; t += 12) {
+            const int rr = t * 2 + (lane >> 5), c = lane & 31;
+            const floatx4 v = *reinterpret_cast<const floatx4*>(tile + rr * 128 + ((c ^ (rr & 7)) << 2));
+            *reinterpret_cast<floatx4*>(slab + (int64_t)(m0 + rr) * p.ldc + n0 + (c << 2)) = v;
+        }
+        return;
+    }
+    if (wave < 4) gemm_epilogue(p, acc, (int64_t)m0 + wx * 64, n0 + wy * 64, lane);
+#undef WRS_RING_BARRIER
+}
+
 // ------------------------------------------------------------------------------------------ ping-pong GEMM, 256x256x32
 // Measured on the 4-wave kernel above (profiles/r01_gemm_*): a wave spends ~95 cycles of ISSUE per 1-KiB direct-to-LDS
 // piece — its 8 pieces per k-tile cost more than the tile's 32 MFMAs — and, being in order, cannot overlap the two; a CU
@@ -506,6 +628,15 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
         return;
     }
     const dim3 grid((unsigned)(8 * cdiv(tiles, 8)), (unsigned)p.ksplit);
+    // decode-step shapes (packed activations) whose grid gives a CU at most one workgroup: loader/consumer ring kernel
+    static const int ring_mode = getenv("WRS_GEMM_RING") ? atoi(getenv("WRS_GEMM_RING")) : 1;  // 0 off, 1 auto, 2 always
+    if (A.packed && A.packed_rows >= round_up(M, 128) && (ring_mode == 2 || (ring_mode == 1 && tiles * p.ksplit <= 256))) {
+        const size_t shmem = 3 * 2048 * 16;
+        static bool attr = false;
+        if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); attr = true; }
+        gemm_f16_ring_kernel<<<grid, 768, shmem, s>>>(p);
+        return;
+    }
     if (A.packed) {
         WRS_REQUIRE(A.packed_rows >= round_up(M, 128), "gemm_f16: packed A must hold a multiple of 128 rows (%ld < %ld)", (long)A.packed_rows, (long)round_up(M, 128));
         gemm_f16_kernel<true><<<grid, 256, 0, s>>>(p);

@@ -501,7 +501,9 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
             // keep >= ~256 workgroups in flight: split K when the tile grid alone is too small (N = D shapes)
             const int64_t tiles = cdiv(rows, 128) * cdiv(N, 128);
             int split = 1;
-            while (tiles * split < 256 && (K / 64) % (split * 2) == 0 && K / 64 / (split * 2) >= 10) split *= 2;
+            // ... but stay within one workgroup per CU: that grid runs on the loader/consumer ring kernel (gemm.hip), whose
+            // k-loop is 1.6x faster, and every extra slice is another fp32 slab to write and reduce
+            while (tiles * split * 2 <= 256 && (K / 64) % (split * 2) == 0 && K / 64 / (split * 2) >= 10) split *= 2;
             e.ksplit = split; e.slab_stride = (int64_t)mp * N;
             launch_gemm_f16(A, w, rows, N, K, e, stream);
             ks = split;
