@@ -348,12 +348,18 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
 // k-tile, loader-bound); 3-slot LDS ring (96 KiB), one workgroup barrier per k-tile.  Used when the grid has at most one
 // workgroup per CU (a 12-wave, 96-KiB workgroup fills a CU; with more tiles the 4-wave kernel's two workgroups per CU win;
 // a 128x256 variant for the N = 3D / 4D shapes spilled and lost: profiles/r01_gemm_ring_decode.log).
-__global__ __launch_bounds__(768) void gemm_f16_ring_kernel(const GemmParams p) {
-    constexpr int STAGE = 2048;  // half8 units per ring slot: 16 activation + 16 weight fragments
+// NC consumer waves (4: one 128x128 tile; 8: 128x256, two consumer waves per SIMD) and NL loader waves.
+template <int NC, int NL>
+__global__ __launch_bounds__(64 * (NC + NL)) void gemm_f16_ring_kernel(const GemmParams p) {
+    constexpr int WFR = 4 * NC;                 // weight fragments per k-tile (16 per 128 columns)
+    constexpr int BN = 32 * NC;                 // tile width
+    constexpr int STAGE = (16 + WFR) * 64;      // half8 units per ring slot
+    constexpr int APL = 16 / NL, WPL = WFR / NL;  // pieces per loader wave per k-tile
+    static_assert(APL * NL == 16 && WPL * NL == WFR, "pieces must divide evenly over the loader waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
     half8* smem = reinterpret_cast<half8*>(gemm_smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int mt_n = (p.M + 127) >> 7, nt_n = (p.N + 127) >> 7;
+    const int mt_n = (p.M + 127) >> 7, nt_n = (p.N + BN - 1) / BN;
     const int tiles = mt_n * nt_n, per_xcd = (tiles + 7) >> 3;
     const int seq = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (seq >= tiles) return;  // whole workgroup, before any barrier
@@ -361,43 +367,49 @@ __global__ __launch_bounds__(768) void gemm_f16_ring_kernel(const GemmParams p) 
     const int band_m0 = band * 8;
     const int band_rows = min(8, mt_n - band_m0);
     const int r = seq - band * 8 * nt_n;
-    const int m0 = (band_m0 + r % band_rows) * 128, n0 = (r / band_rows) * 128;
+    const int m0 = (band_m0 + r % band_rows) * 128, n0 = (r / band_rows) * BN;
     const int nk = p.K / 64 / p.ksplit;
     const int kt0 = blockIdx.y * nk;
 #define WRS_RING_BARRIER() asm volatile("s_barrier" ::: "memory")
     floatx4 acc[4][4];
-    const int wy = (wave & 3) >> 1, wx = wave & 1;
-    if (wave >= 4) {
+    const int wy = wave >> 1, wx = wave & 1;  // consumer wave: 64-column block, 64-row half
+    if (wave >= NC) {
         // ---------------- loader waves
-        const int lw = wave - 4;
-        const half_t* a_ptr[2];
-        const half_t* w_ptr[2];
+        const int lw = wave - NC;
+        const half_t* a_ptr[APL];
+        const half_t* w_ptr[WPL];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int f = lw * 2 + j;  // fragment 0..15: (tile of 16 rows/columns f>>1, k-step f&1)
+        for (int j = 0; j < APL; ++j) {
+            const int f = lw * APL + j;  // fragment: (tile of 16 rows f>>1, k-step f&1)
             a_ptr[j] = p.a + ((int64_t)(m0 / 16 + (f >> 1)) * p.ksteps + (f & 1)) * 512 + lane * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) {
+            const int f = lw * WPL + j;  // fragment: (tile of 16 columns f>>1, k-step f&1)
             w_ptr[j] = p.wp + ((int64_t)(n0 / 16 + (f >> 1)) * p.ksteps + (f & 1)) * 512 + lane * 8;
         }
         auto issue = [&](int u) {
             half8* st_ = smem + (u % 3) * STAGE;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < APL; ++j)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[j] + (int64_t)(kt0 + u) * 1024),
-                                                 (__attribute__((address_space(3))) void*)(st_ + (lw * 2 + j) * 64), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(st_ + (lw * APL + j) * 64), 16, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WPL; ++j)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[j] + (int64_t)(kt0 + u) * 1024),
-                                                 (__attribute__((address_space(3))) void*)(st_ + 1024 + (lw * 2 + j) * 64), 16, 0, 0);
-            }
+                                                 (__attribute__((address_space(3))) void*)(st_ + 1024 + (lw * WPL + j) * 64), 16, 0, 0);
         };
+        static_assert(APL + WPL == 4 || APL + WPL == 12, "vmcnt immediates below");
+#define WRS_RING_KEEP_ONE() do { if (APL + WPL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); } while (0)
         issue(0);
-        if (nk > 1) issue(1);
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (nk > 1) { issue(1); WRS_RING_KEEP_ONE(); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WRS_RING_BARRIER();  // tile 0 has landed
         for (int t = 0; t < nk; ++t) {
             // slot of tile t+2 = slot of tile t-1, which the consumers left at the previous barrier
             if (t + 2 < nk) {
                 issue(t + 2);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile t+1 landed, tile t+2 in flight
+                WRS_RING_KEEP_ONE();  // tile t+1 landed, tile t+2 in flight
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -434,10 +446,10 @@ __global__ __launch_bounds__(768) void gemm_f16_ring_kernel(const GemmParams p) 
         }
     }
     // every wave is past the last barrier of the loop: the ring is free
-    if (p.ksplit > 1 && m0 + 128 <= p.M && n0 + 128 <= p.N && (p.ldc & 3) == 0) {
-        // split-K slab of a full tile: transposed through LDS, stored as whole 512-byte rows by all 12 waves
+    if (NC == 4 && p.ksplit > 1 && m0 + 128 <= p.M && n0 + 128 <= p.N && (p.ldc & 3) == 0) {
+        // split-K slab of a full tile: transposed through LDS, stored as whole 512-byte rows by all waves
         float* tile = reinterpret_cast<float*>(smem);  // [128][128] fp32 = 64 KiB
-        if (wave < 4) {
+        if (wave < NC) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int rr = wx * 64 + jj * 16 + (lane & 15);
@@ -450,15 +462,16 @@ __global__ __launch_bounds__(768) void gemm_f16_ring_kernel(const GemmParams p) 
         }
         __syncthreads();
         float* slab = reinterpret_cast<float*>(p.c) + (int64_t)blockIdx.y * p.slab_stride;
-        for (int t = wave; t < 64; t += 12) {
+        for (int t = wave; t < 64; t += NC + NL) {
             const int rr = t * 2 + (lane >> 5), c = lane & 31;
             const floatx4 v = *reinterpret_cast<const floatx4*>(tile + rr * 128 + ((c ^ (rr & 7)) << 2));
             *reinterpret_cast<floatx4*>(slab + (int64_t)(m0 + rr) * p.ldc + n0 + (c << 2)) = v;
         }
         return;
     }
-    if (wave < 4) gemm_epilogue(p, acc, (int64_t)m0 + wx * 64, n0 + wy * 64, lane);
+    if (wave < NC) gemm_epilogue(p, acc, (int64_t)m0 + wx * 64, n0 + wy * 64, lane);
 #undef WRS_RING_BARRIER
+#undef WRS_RING_KEEP_ONE
 }
 
 // ------------------------------------------------------------------------------------------ ping-pong GEMM, 256x256x32
@@ -628,14 +641,19 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
         return;
     }
     const dim3 grid((unsigned)(8 * cdiv(tiles, 8)), (unsigned)p.ksplit);
-    // decode-step shapes (packed activations) whose grid gives a CU at most one workgroup: loader/consumer ring kernel
+    // decode-step shapes (packed activations) whose grid gives a CU at most one workgroup: loader/consumer ring kernels
     static const int ring_mode = getenv("WRS_GEMM_RING") ? atoi(getenv("WRS_GEMM_RING")) : 1;  // 0 off, 1 auto, 2 always
-    if (A.packed && A.packed_rows >= round_up(M, 128) && (ring_mode == 2 || (ring_mode == 1 && tiles * p.ksplit <= 256))) {
-        const size_t shmem = 3 * 2048 * 16;
-        static bool attr = false;
-        if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); attr = true; }
-        gemm_f16_ring_kernel<<<grid, 768, shmem, s>>>(p);
-        return;
+    if (A.packed && A.packed_rows >= round_up(M, 128) && ring_mode != 0) {
+        if (tiles * p.ksplit <= 256 || (ring_mode == 2 && p.ksplit > 1)) {
+            const size_t shmem = 3 * 2048 * 16;
+            static bool attr = false;
+            if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_ring_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); attr = true; }
+            gemm_f16_ring_kernel<4, 8><<<grid, 768, shmem, s>>>(p);
+            return;
+        }
+        // (a 128x256 instantiation, 8 consumer + 4 loader waves, only equals the 4-wave kernel on the N = 3D / 4D shapes —
+        // 24 vs 24 us, 29 vs 30 us: both are dominated by the fp32 / GELU epilogue — and is not used:
+        // profiles/r01_gemm_ring_decode.log)
     }
     if (A.packed) {
         WRS_REQUIRE(A.packed_rows >= round_up(M, 128), "gemm_f16: packed A must hold a multiple of 128 rows (%ld < %ld)", (long)A.packed_rows, (long)round_up(M, 128));
