@@ -284,6 +284,7 @@ def main():
                        "overlap": "next step's encoder on a side stream during this step's decode" if overlap else "none"},
             "roofline": rl,
             "last_step_split_ms": {k: round(v, 2) for k, v in split.items()},
+            "hbm_free_gb_after_run": round(torch.cuda.mem_get_info(dev)[0] / 1e9, 1),
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(dims, args.beam, args.sample_len)

@@ -688,7 +688,7 @@ int skinny_m_pad(int M) {
     static const int opts[] = {1, 2, 4, 6, 8, 10, 12, 16, 20};
     for (int o : opts)
         if (o * 16 >= M) return o * 16;
-    if (M <= 1280) return (M + 159) / 160 * 160;  // beyond 320 rows: multiples of 10 row tiles (row blocks)
+    if (M <= 2560) return (M + 159) / 160 * 160;  // beyond 320 rows: multiples of 10 row tiles (row blocks)
     return -1;
 }
 

@@ -410,7 +410,7 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     WRS_REQUIRE(a_cap >= 1 && group >= 1 && group <= 16, "decoder state: bad capacity (audios %d, group %d)", a_cap, group);
     const int r_cap = a_cap * group;
     const int m_pad = skinny_m_pad(r_cap);
-    WRS_REQUIRE(m_pad > 0, "decoder state: %d rows exceed the 1280-row limit of the decode kernels", r_cap);
+    WRS_REQUIRE(m_pad > 0, "decoder state: %d rows exceed the 2560-row limit of the decode kernels", r_cap);
     use();
     st.a_cap = a_cap; st.group = group; st.r_cap = r_cap; st.m_pad = m_pad;
     const size_t per_head = packed_kv_halfs_per_head(T);
