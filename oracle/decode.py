@@ -132,6 +132,15 @@ class BeamSearchTokenExtractor:
             self.finished_sequences = [dict() for _ in range(n_audio)]  # insertion-ordered
         logprobs = logits.log_softmax(dim=-1, dtype=torch.float32)  # :37
         lp, tk = logprobs.topk(self.beam_size + 1, dim=-1, largest=True, sorted=True)  # :62-65 (per row)
+        return self.update_from_candidates(model, tokens, lp, tk, sum_logprobs)
+
+    def update_from_candidates(self, model, tokens, lp, tk, sum_logprobs):
+        """the rest of `update` given each row's sorted top-(beam+1) (log-prob, token) lists (test aid: lets the host
+        sequencer of the build be checked against this one on arbitrary candidate lists, without a model)."""
+        B = tokens.shape[0]
+        n_audio = B // self.beam_size
+        if self.finished_sequences is None:
+            self.finished_sequences = [dict() for _ in range(n_audio)]
         next_tokens, source_indices, finished_all = beam_select(tokens.tolist(), sum_logprobs, lp, tk, self.beam_size, self.eot)
         new_tokens = torch.tensor(next_tokens, dtype=torch.int64)  # :109
         src = torch.tensor(source_indices, dtype=torch.int64)

@@ -117,3 +117,89 @@ def test_oracle_sot_sequence_tail_and_languages():
     other = task.run_batch(mel)
     assert torch.equal(base[1].tokens, other[1].tokens) and abs(base[1].sum_logprob - other[1].sum_logprob) < 1e-5
     assert not (torch.equal(base[0].tokens, other[0].tokens) and base[0].sum_logprob == other[0].sum_logprob)
+
+
+def _sequencer_cpp(ids, opts_kw, initial, n_audio, lp, tk):
+    """run the library's host sequencer (csrc/decode.cpp update_beam / finalize / rank) on given candidate lists."""
+    import ctypes as C
+    import whisper_rs_amd as W
+    from whisper_rs_amd import _lib as L
+    from whisper_rs_amd.api import _fill_decode_options, _ids_c
+    lib = W.load_library()
+    keep = []
+    c = _fill_decode_options(W.DecodeOptions(**opts_kw), keep)
+    cid = _ids_c(ids)
+    steps, R, k = lp.shape
+    lp = np.ascontiguousarray(lp, np.float32); tk = np.ascontiguousarray(tk, np.int32)
+    init = np.ascontiguousarray(initial, np.int64)
+    res = L.DecodeResultC()
+    tt, ts, tl = np.zeros((steps, R), np.int32), np.zeros((steps, R), np.int32), np.zeros((steps, R), np.float32)
+    fn = lib.wrs_debug_sequencer_run
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p] * 6
+    L.check(fn(C.byref(cid), C.byref(c), init.ctypes.data, init.size, n_audio, steps, lp.ctypes.data, tk.ctypes.data, C.byref(res),
+               tt.ctypes.data, ts.ctypes.data, tl.ctypes.data))
+    outs = []
+    for i in range(res.n_outputs):
+        o = res.outputs[i]
+        toks = np.ctypeslib.as_array(o.tokens, shape=(o.n_tokens,)).copy() if o.n_tokens > 0 else np.zeros(0, np.int64)
+        outs.append((toks, o.sum_logprob, o.avg_logprob))
+    n = res.n_steps
+    lib.wrs_decode_result_free(C.byref(res))
+    return outs, n, tt[:n], ts[:n], tl[:n]
+
+
+@pytest.mark.parametrize("G,patience,len_penalty,seed", [(5, 1.0, None, 0), (5, 2.0, None, 1), (3, 1.0, 1.0, 2), (2, 1.5, None, 3), (5, 1.0, 0.6, 4)])
+def test_cpp_host_sequencer_matches_oracle_on_random_candidates(G, patience, len_penalty, seed):
+    """The C++ beam-search sequencer (update: dedup by sequence, f64 scores stored as f32, EOT -> finished, patience;
+    finalize; MaximumLikelihoodRanker — reference beam_search.rs:22-206, max_likelihood.rs:13-34) against the oracle on
+    random candidate lists with frequent collisions and early EOTs.  No model, no device: bit-exact."""
+    import torch
+    import whisper_rs_amd as W
+    from helpers import oracle_ids
+    from oracle import decode as OD
+    rng = np.random.default_rng(seed)
+    ids = W.TokenIds.english()
+    n_audio, steps, k = 4, 18, G + 1
+    R = n_audio * G
+    pool = np.array(list(range(100, 112)) + [ids.eot] * 2)  # tiny vocabulary: colliding sequences, EOT fairly often
+    lp = np.zeros((steps, R, k), np.float32)
+    tk = np.zeros((steps, R, k), np.int32)
+    for s in range(steps):
+        for r in range(R):
+            src = r if s > 0 else (r // G) * G            # step 0: the beams of an audio share one prefill row
+            if s == 0 and r != src:
+                lp[s, r], tk[s, r] = lp[s, src], tk[s, src]
+                continue
+            cand = rng.permutation(np.unique(pool))[:k]
+            if s < 2:
+                cand = cand[cand != ids.eot]
+                cand = np.concatenate([cand, rng.permutation(np.arange(200, 200 + k))])[:k]
+            tk[s, r] = cand
+            lp[s, r] = -np.sort(rng.uniform(0.05, 4.0, size=k)).astype(np.float32)
+    initial = [ids.sot]
+    got, n_cpp, tt, ts, tl = _sequencer_cpp(ids, dict(sample_len=steps, token_extract_mode=W.TokenExtractMode.BeamSearch(G, patience),
+                                                      len_penalty=len_penalty), initial, n_audio, lp, tk)
+    # oracle
+    ex = OD.BeamSearchTokenExtractor(G, ids.eot, patience)
+    tokens = torch.tensor([initial] * R, dtype=torch.int64)
+    slp = torch.zeros(R, dtype=torch.float32)
+    n_or = 0
+    for s in range(steps):
+        tokens, completed = ex.update_from_candidates(None, tokens, torch.from_numpy(lp[s]), torch.from_numpy(tk[s].astype(np.int64)), slp)
+        n_or = s + 1
+        if completed:
+            break
+    assert n_cpp == n_or
+    for s in range(n_or):
+        np.testing.assert_array_equal(tt[s], ex.trace[s][0].numpy())
+        np.testing.assert_array_equal(ts[s], ex.trace[s][1].numpy())
+        np.testing.assert_array_equal(tl[s], ex.trace[s][2].numpy())
+    cands, lps = ex.finalize(tokens.reshape(n_audio, G, -1), slp.reshape(n_audio, G))
+    sliced = [[t[1:int((t == ids.eot).nonzero()[0, 0])] for t in seqs] for seqs in cands]
+    sel = OD.MaximumLikelihoodRanker(len_penalty).rank(sliced, lps)
+    for a in range(n_audio):
+        want = sliced[a][sel[a]].numpy()
+        np.testing.assert_array_equal(got[a][0], want)
+        assert got[a][1] == float(lps[a][sel[a]])
+        assert abs(got[a][2] - float(lps[a][sel[a]]) / (len(want) + 1.0)) < 1e-12

@@ -476,6 +476,20 @@ int wrs_debug_decode_forced(wrs_decode_task* t, const float* mel, int n_audio, i
         t->t.run_forced(n_audio, n_steps, ftok, fsrc, out_lp, out_id, out_no_speech);
     });
 }
+// host sequencer alone (no device needed): see DecodeTask::simulate.  Trace of the run through out_* ([steps][rows]).
+int wrs_debug_sequencer_run(const wrs_token_ids* ids, const wrs_decode_options* opt, const int64_t* initial, int32_t n_initial, int32_t n_audio,
+                            int32_t n_steps, const float* lp, const int32_t* id, wrs_decode_result* out, int32_t* out_tokens,
+                            int32_t* out_sources, float* out_slp) {
+    return guarded([&] {
+        WRS_REQUIRE(ids && opt && out, "null argument");
+        DecodeTask t;
+        t.simulate(*ids, *opt, initial, n_initial, n_audio, n_steps, lp, id, out);
+        const size_t n = t.tr_tokens.size();
+        if (out_tokens) memcpy(out_tokens, t.tr_tokens.data(), n * 4);
+        if (out_sources) memcpy(out_sources, t.tr_src.data(), n * 4);
+        if (out_slp) memcpy(out_slp, t.tr_slp.data(), n * 4);
+    });
+}
 int wrs_debug_set_encoder_stop(wrs_model* h, int n_launches) { if (h) h->m.debug_enc_stop = n_launches; return 0; }
 // copy an internal encoder workspace buffer to host as f32. which: 0 x(f32) 1 xn 2 qkv 3 att 4 h 5 c1 6 mel_t 7 xa16
 int wrs_debug_read_encoder(wrs_model* h, int which, float* out, int64_t n) {

@@ -275,10 +275,8 @@ void DecodeTask::record_trace(int R) {
 
 // BeamSearchTokenExtractor::update (beam_search.rs:22-149).  step0: every beam of an audio reads the
 // audio's single prefill row (identical logits for identical rows; the reference computes them 5x).
-bool DecodeTask::update_beam(int n_audio, bool step0) {
+bool DecodeTask::update_beam(int n_audio, bool step0, const float* lp, const int* id) {
     const int G = group, k = G + 1;
-    const float* lp = st.topk_lp();
-    const int* id = st.topk_id();
     struct Cand { int beam; int64_t token; double score; int source; };
     std::vector<std::vector<int64_t>> new_rows((size_t)n_audio * G);
     std::vector<float> new_slp((size_t)n_audio * G, 0.f);
@@ -346,10 +344,8 @@ bool DecodeTask::update_beam(int n_audio, bool step0) {
 // GreedyTokenExtractor::update (greedy.rs:17-51), temperature 0.  completed = every row's last
 // token is EOT (OpenAI); the literal `tokens.eq(eot).all()` can never hold and the
 // outputs are identical either way because finished rows keep emitting EOT with no logprob added.
-bool DecodeTask::update_greedy(int n_audio, bool step0) {
+bool DecodeTask::update_greedy(int n_audio, bool step0, const float* lp, const int* id) {
     const int G = group;
-    const float* lp = st.topk_lp();
-    const int* id = st.topk_id();
     bool completed = true;
     for (int r = 0; r < n_audio * G; ++r) {
         const int trow = step0 ? r / G : r;
@@ -445,7 +441,7 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
     t_prefill_ms = now_ms() - tA;
 
     tA = now_ms();
-    bool completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, true) : update_greedy(n_audio, true);
+    bool completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, true, st.topk_lp(), st.topk_id()) : update_greedy(n_audio, true, st.topk_lp(), st.topk_id());
     record_trace(R);
     n_steps = 1;
     t_host_ms += now_ms() - tA;
@@ -467,7 +463,7 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
         step_decode(R);
         const double t2 = now_ms();
         if (m->timer && m->timer->enabled) m->timer->collect();
-        completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, false) : update_greedy(n_audio, false);
+        completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, false, st.topk_lp(), st.topk_id()) : update_greedy(n_audio, false, st.topk_lp(), st.topk_id());
         record_trace(R);
         n_steps = i + 1;
         t_steps_ms += t2 - t1;
@@ -476,6 +472,53 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
     }
     finalize(n_audio, out);
     out->n_steps = n_steps;
+}
+
+// Host sequencer alone (test hook, no device): the candidate lists a device step would have produced are given by the
+// caller — lp/id [n_steps][rows][k], k = beam + 1 (beam search) or 1 (greedy); step 0 reads row a*G of audio a like the
+// real loop (all beams of an audio are one prefill row) — and update / finalize / rank run exactly as in run_decode.
+void DecodeTask::simulate(const wrs_token_ids& tid, const wrs_decode_options& o, const int64_t* initial, int n_initial, int n_audio,
+                          int n_steps, const float* lp, const int32_t* id, wrs_decode_result* out) {
+    WRS_REQUIRE(initial && n_initial >= 1 && n_audio >= 1 && n_steps >= 1 && lp && id && out, "simulate: bad argument");
+    m = nullptr;
+    ids = tid;
+    mode = o.extract_mode;
+    group = o.group_size;
+    WRS_REQUIRE(group >= 1 && group <= 7, "simulate: group/beam size %d not in 1..7", group);
+    patience = o.patience;
+    has_len_penalty = o.has_len_penalty != 0;
+    len_penalty = o.len_penalty;
+    initial_tokens.assign(initial, initial + n_initial);
+    sample_begin = n_initial;
+    const int G = group, R = n_audio * G, k = (mode == WRS_EXTRACT_BEAM_SEARCH) ? G + 1 : 1;
+    memset(out, 0, sizeof(*out));
+    rows.assign(R, initial_tokens);
+    sum_logprobs.assign(R, 0.f);
+    sources.assign(R, 0);
+    finished.assign(n_audio, {});
+    no_speech.assign(n_audio, NAN);
+    tr_tokens.clear(); tr_src.clear(); tr_slp.clear();
+    tr_rows = R;
+    n_steps = std::max(1, n_steps);
+    std::vector<float> lp0((size_t)R * k);
+    std::vector<int> id0((size_t)R * k);
+    int taken = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        const float* l = lp + (size_t)s * R * k;
+        const int32_t* d = id + (size_t)s * R * k;
+        if (s == 0) {  // compact to one row per audio, as the prefill leaves it in the pinned candidate buffer
+            for (int a = 0; a < n_audio; ++a)
+                for (int c = 0; c < k; ++c) { lp0[(size_t)a * k + c] = l[(size_t)a * G * k + c]; id0[(size_t)a * k + c] = d[(size_t)a * G * k + c]; }
+            l = lp0.data(); d = id0.data();
+        }
+        const bool completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, s == 0, l, d) : update_greedy(n_audio, s == 0, l, d);
+        record_trace(R);
+        taken = s + 1;
+        if (completed) break;
+    }
+    this->n_steps = taken;
+    finalize(n_audio, out);
+    out->n_steps = taken;
 }
 
 // Teacher-forced run (test hook).  Step s uses forced tokens/sources [s][R] as the outcome of step s; the
@@ -609,7 +652,7 @@ void DecodeTask::finalize(int n_audio, wrs_decode_result* out) {
         o.sum_logprob = cands[i][best].score;
         o.avg_logprob = cands[i][best].score / ((double)o.n_tokens + 1.0);
         o.no_speech_prob = no_speech[i];
-        o.audio_features_device = m->enc_ws.xa32.as<float>() + (size_t)i * m->T * m->D;
+        o.audio_features_device = m ? m->enc_ws.xa32.as<float>() + (size_t)i * m->T * m->D : nullptr;
         o.text = tokenizer ? dup_cstr(tokenizer->decode(o.tokens, o.n_tokens)) : nullptr;  // decode/mod.rs:404
     }
 }

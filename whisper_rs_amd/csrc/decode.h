@@ -95,8 +95,10 @@ struct DecodeTask {
 
     void upload_step(int rows_n);
     void step_decode(int rows_n);  // decoder_step + filter_topk for rows_n = n_audio*group rows (graph-replayed)
-    bool update_beam(int n_audio, bool step0);
-    bool update_greedy(int n_audio, bool step0);
+    bool update_beam(int n_audio, bool step0, const float* lp, const int* id);
+    bool update_greedy(int n_audio, bool step0, const float* lp, const int* id);
+    void simulate(const wrs_token_ids& tid, const wrs_decode_options& o, const int64_t* initial, int n_initial, int n_audio, int n_steps,
+                  const float* lp, const int32_t* id, wrs_decode_result* out);
     void finalize(int n_audio, wrs_decode_result* out);
     void record_trace(int R);
 };
