@@ -203,3 +203,80 @@ def test_cpp_host_sequencer_matches_oracle_on_random_candidates(G, patience, len
         np.testing.assert_array_equal(got[a][0], want)
         assert got[a][1] == float(lps[a][sel[a]])
         assert abs(got[a][2] - float(lps[a][sel[a]]) / (len(want) + 1.0)) < 1e-12
+
+
+def _transcribe_bookkeeping_cpp(ts_begin, n_audio_ctxs, n_frames, prompt, windows, tokenizer=None):
+    import ctypes as C
+    import whisper_rs_amd as W
+    from whisper_rs_amd import _lib as L
+    lib = W.load_library()
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(w, np.int64) for w in windows]) if windows else np.zeros(0, np.int64))
+    lens = np.ascontiguousarray([len(w) for w in windows], np.int32)
+    pr = np.ascontiguousarray(prompt or [], np.int64)
+    out = L.TranscribeOutputC()
+    fn = lib.wrs_debug_transcribe_bookkeeping
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.check(fn(ts_begin, n_audio_ctxs, n_frames, pr.ctypes.data if pr.size else None, pr.size, flat.ctypes.data, lens.ctypes.data, len(windows),
+               tokenizer._h if tokenizer is not None else None, C.byref(out)))
+    toks = np.ctypeslib.as_array(out.tokens, shape=(out.n_tokens,)).copy() if out.n_tokens else np.zeros(0, np.int64)
+    segs = [(s.seek, s.start_time, s.end_time, s.start_token, s.end_token, None if not s.text else C.string_at(s.text).decode())
+            for s in (out.segments[i] for i in range(out.n_segments))]
+    seeks = [out.window_seek[i] for i in range(out.n_windows)]
+    text = None if not out.text else C.string_at(out.text).decode()
+    lib.wrs_transcribe_output_free(C.byref(out))
+    return toks, segs, seeks, text
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_cpp_transcribe_bookkeeping_matches_oracle(monkeypatch, seed):
+    """seek / segment / token accumulation of the long-form loop (reference transcribe.rs:151-234) in the C++ host code
+    (csrc/transcribe.cpp, run through a device-free hook with scripted window outputs) against the oracle loop:
+    consecutive-timestamp slicing, single trailing timestamp, no timestamp at all, prompts."""
+    import whisper_rs_amd as W
+    from whisper_rs_amd.consts import MODEL_DIMS
+    rng = np.random.default_rng(seed)
+    ids = oracle_ids()
+    ts = ids.ts_begin
+    n_frames = 20000
+
+    def window():
+        t, toks = int(rng.integers(0, 20)), []
+        toks.append(ts + t)
+        for _ in range(int(rng.integers(1, 5))):
+            toks += [int(x) for x in rng.integers(100, 5000, size=int(rng.integers(1, 6)))]
+            kind = rng.integers(0, 4)
+            t += int(rng.integers(5, 400))
+            t = min(t, 1500)
+            if kind == 0:
+                toks += [ts + t, ts + t]          # closes a segment and opens the next
+            elif kind == 1:
+                toks += [ts + t]                  # a lone timestamp
+        if rng.integers(0, 3) == 0:
+            toks = [x for x in toks if x < ts] or [123]   # a window without any timestamp
+        return toks
+
+    windows = [window() for _ in range(40)]
+    prompt = [int(x) for x in rng.integers(100, 5000, size=3)] if seed % 2 else None
+    t = OT.TranscribeTask.__new__(OT.TranscribeTask)
+    class M: dims = MODEL_DIMS["nano"]
+    t.model, t.ids, t.prompt_tokens, t.condition_on_prev_text = M, ids, prompt, True
+    t.decode_task = _FakeDecode([list(w) for w in windows])
+    monkeypatch.setattr(OT.A, "log_mel_spectrogram", lambda a, f: torch.zeros(80, n_frames))
+    want = t.run(torch.zeros(16000))
+    toks, segs, seeks, text = _transcribe_bookkeeping_cpp(ts, M.dims.n_audio_ctxs, n_frames, prompt, windows)
+    assert seeks == [w[0] for w in want.windows]
+    np.testing.assert_array_equal(toks, want.tokens.numpy())
+    assert len(segs) == len(want.segments) and text is None
+    for g, o in zip(segs, want.segments):
+        assert g[0] == o.seek and g[3] == o.start_token and g[4] == o.end_token
+        assert abs(g[1] - o.start_time) < 1e-9 and abs(g[2] - o.end_time) < 1e-9
+    # with a tokenizer attached the texts are the decode of exactly the reference's slices (transcribe.rs:200,227,236)
+    from helpers import synthetic_tokenizer_json
+    tok = W.Tokenizer.new_from_bytes(synthetic_tokenizer_json())
+    toks2, segs2, _, text2 = _transcribe_bookkeeping_cpp(ts, M.dims.n_audio_ctxs, n_frames, prompt, windows, tok)
+    cstr = lambda t: t.split("\0")[0]  # the struct carries NUL-terminated strings; random ids can decode to a NUL byte
+    assert text2 == cstr(tok.decode(toks2))
+    for g in segs2:
+        if g[3] > 0:
+            assert g[5] == cstr(tok.decode(toks2[g[3] - 1:g[4]]))

@@ -490,6 +490,14 @@ int wrs_debug_sequencer_run(const wrs_token_ids* ids, const wrs_decode_options* 
         if (out_slp) memcpy(out_slp, t.tr_slp.data(), n * 4);
     });
 }
+// long-form bookkeeping alone (no device needed): see simulate_transcribe
+int wrs_debug_transcribe_bookkeeping(int32_t ts_begin, int64_t n_audio_ctxs, int64_t n_frames, const int64_t* prompt, int64_t n_prompt,
+                                     const int64_t* window_tokens, const int32_t* window_lens, int32_t n_windows, const wrs_tokenizer* tok,
+                                     wrs_transcribe_output* out) {
+    return guarded([&] {
+        simulate_transcribe(ts_begin, n_audio_ctxs, n_frames, prompt, n_prompt, window_tokens, window_lens, n_windows, tok ? &tok->t : nullptr, out);
+    });
+}
 int wrs_debug_set_encoder_stop(wrs_model* h, int n_launches) { if (h) h->m.debug_enc_stop = n_launches; return 0; }
 // copy an internal encoder workspace buffer to host as f32. which: 0 x(f32) 1 xn 2 qkv 3 att 4 h 5 c1 6 mel_t 7 xa16
 int wrs_debug_read_encoder(wrs_model* h, int which, float* out, int64_t n) {

@@ -96,6 +96,30 @@ static int64_t absorb_window(OutBuilder& ob, const int64_t* seg, int n, int64_t 
     return WRS_N_FRAMES;
 }
 
+// Bookkeeping of the long-form loop alone (test hook, no device): the windows' decoded token lists are given by the caller
+// in the order the loop would request them; seek / segments / accumulated tokens evolve exactly as in TranscribeTask::run.
+void simulate_transcribe(int ts_begin, int64_t n_audio_ctxs, int64_t n_frames, const int64_t* prompt, int64_t n_prompt,
+                         const int64_t* window_tokens, const int32_t* window_lens, int32_t n_windows, const Tokenizer* tok,
+                         wrs_transcribe_output* out) {
+    WRS_REQUIRE(out && n_audio_ctxs > 0 && n_frames > 0 && (window_tokens || n_windows == 0) && n_windows >= 0, "simulate_transcribe: bad argument");
+    const int64_t input_stride = WRS_N_FRAMES / n_audio_ctxs;
+    const double time_precision = (double)input_stride * kQuantum;
+    OutBuilder ob;
+    ob.tok = tok;
+    if (prompt && n_prompt > 0) ob.tokens.assign(prompt, prompt + n_prompt);
+    int64_t seek = 0, off = 0;
+    for (int w = 0; w < n_windows && seek < n_frames; ++w) {
+        ob.wseek.push_back(seek);
+        ob.wavg.push_back(0.0);
+        ob.wns.push_back(0.0);
+        const int64_t adv = absorb_window(ob, window_tokens + off, window_lens[w], seek, ts_begin, input_stride, time_precision, false);
+        off += window_lens[w];
+        if (adv == 0) break;
+        seek += adv;
+    }
+    ob.emit(out);
+}
+
 int64_t TranscribeTask::prepare_mel(const float* audio, int64_t n) {
     WRS_REQUIRE(audio && n >= 201, "transcribe: need at least 201 samples");
     m->use();

@@ -21,4 +21,8 @@ struct TranscribeTask {
     void run_chunked(const float* audio, int64_t n, int batch, wrs_transcribe_output* out);
 };
 
+void simulate_transcribe(int ts_begin, int64_t n_audio_ctxs, int64_t n_frames, const int64_t* prompt, int64_t n_prompt,
+                         const int64_t* window_tokens, const int32_t* window_lens, int32_t n_windows, const Tokenizer* tok,
+                         wrs_transcribe_output* out);
+
 }  // namespace wrs
