@@ -264,7 +264,7 @@ def main():
             # prescribes for wide coalesced reads; WRITE_SIZE is negligible for this kernel), scaled to this batch
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_b32.json")))["cross_attention_decode"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_b256.json")))["cross_attention_decode"]
                 traffic = pmc["fetch_bytes_corrected_per_launch"] * args.batch / pmc["batch"] if args.model == "large-v2" else None
             except Exception:
                 pass
