@@ -23,6 +23,16 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// hipFuncSetAttribute is per device: a process that drives several GPUs (window pool) must raise the dynamic-LDS limit of a
+// kernel on each of them, once.  `done` is the kernel's own table of 64 flags.
+static void allow_dynamic_lds(const void* kernel, size_t bytes, bool (&done)[64]) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || done[dev]) return;
+    HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done[dev] = true;
+}
+
 // ------------------------------------------------------------------------------------------ packing
 size_t packed_weight_halfs(int64_t n_pad, int64_t k_pad) { return (size_t)n_pad * (size_t)k_pad; }
 
@@ -635,8 +645,8 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     if (!A.packed && N % 256 == 0 && (K / 32) % p.ksplit == 0 && (pp2_mode == 2 || (pp2_mode == 1 && pp2_tiles * p.ksplit >= gemm_pp2_min_wgs))) {
         const dim3 g((unsigned)(8 * cdiv(pp2_tiles, 8)), (unsigned)p.ksplit);
         const size_t shmem = 4 * 2048 * 16;
-        static bool attr = false;
-        if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); attr = true; }
+        static bool attr[64] = {};
+        allow_dynamic_lds(reinterpret_cast<const void*>(gemm_f16_pp2_kernel), shmem, attr);
         gemm_f16_pp2_kernel<<<g, 512, shmem, s>>>(p);
         return;
     }
@@ -646,8 +656,8 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     if (A.packed && A.packed_rows >= round_up(M, 128) && ring_mode != 0) {
         if (tiles * p.ksplit <= 256 || (ring_mode == 2 && p.ksplit > 1)) {
             const size_t shmem = 3 * 2048 * 16;
-            static bool attr = false;
-            if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_ring_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); attr = true; }
+            static bool attr[64] = {};
+            allow_dynamic_lds(reinterpret_cast<const void*>(gemm_f16_ring_kernel<4, 8>), shmem, attr);
             gemm_f16_ring_kernel<4, 8><<<grid, 768, shmem, s>>>(p);
             return;
         }
@@ -949,11 +959,8 @@ template <int MT, int KPS>
 static void launch_dec(const half_t* a, const half_t* wp, float* slab, int M, int N, int n_pad, int ksteps, int mtiles, int m_pad,
                        hipStream_t s) {
     const size_t shmem = (size_t)(MT + 4) * KPS * 1024;  // weight fragments of 4 waves + activation panel
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dec_kernel<MT, KPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
-    }
+    static bool attr_set[64] = {};
+    allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_dec_kernel<MT, KPS>), shmem, attr_set);
     dim3 grid((unsigned)(n_pad / 64), (unsigned)(ksteps / KPS), (unsigned)(mtiles / MT));
     gemm_dec_kernel<MT, KPS><<<grid, 256, shmem, s>>>(a, wp, slab, M, N, ksteps, m_pad);
 }
