@@ -323,6 +323,9 @@ typedef struct wrs_transcribe_output {
     double* window_no_speech_prob;
     int64_t n_windows;
     char* text; /* `TranscribeOutput.text` = tokenizer.decode(tokens) (transcribe.rs:236); NULL unless a tokenizer is attached */
+    /* 1: the loop stopped before the end of the audio — a window ended in a <|0.00|> timestamp pair (seek advance 0, on
+     * which the reference loops forever, transcribe.rs:206) or 10 000 windows were decoded: the rest is NOT transcribed */
+    int32_t truncated;
 } wrs_transcribe_output;
 
 typedef struct wrs_transcribe_task wrs_transcribe_task;
@@ -336,6 +339,10 @@ int wrs_transcribe_task_set_tokenizer(wrs_transcribe_task* t, const wrs_tokenize
 int wrs_transcribe_task_set_prompt_text(wrs_transcribe_task* t, const char* utf8);
 /* `TranscribeTask::run(&audio)` (transcribe.rs:103-243): the sequential long-form loop. audio [n] f32 host. */
 int wrs_transcribe_task_run(wrs_transcribe_task* t, const float* audio, int64_t n_samples, wrs_transcribe_output* out);
+/* the same loop from a caller-supplied log-mel spectrogram [80, n_frames] f32 host (run_inner after its
+ * `log_mel_spectrogram` call, transcribe.rs:113-243): for callers that keep spectrograms, and for parity tests on the
+ * reference's own spectrogram fixture (test/data/mel-spectrogram.csv). */
+int wrs_transcribe_task_run_mel(wrs_transcribe_task* t, const float* mel, int64_t n_frames, wrs_transcribe_output* out);
 /* fixed-stride variant (= the reference's `seek += N_FRAMES` branch with conditioning off,
  * transcribe.rs:231): windows are independent, decoded `batch` at a time; this is what shards over GPUs. */
 int wrs_transcribe_task_run_chunked(wrs_transcribe_task* t, const float* audio, int64_t n_samples, int32_t batch,

@@ -46,6 +46,11 @@ class TranscribeTask:
     def run_inner(self, audio):
         filt = A.mel_filter()  # :111
         mel = A.log_mel_spectrogram(audio, filt)  # :112 (whole file, global max)
+        return self.run_mel(mel)
+
+    def run_mel(self, mel):
+        """run_inner from :113 on, given the spectrogram (test aid: lets the loop run on the reference's own
+        spectrogram fixture, whose WAV the reference does not ship)."""
         n_frames = mel.shape[1]
         QUANTUM = A.HOP_LENGTH / A.SAMPLE_RATE  # :117
         input_stride = A.N_FRAMES // self.model.dims.n_audio_ctxs  # :120

@@ -5,9 +5,13 @@ whisper_rs_amd.synth, so only outputs are stored.  Run from the repo root in the
 
     python scripts/make_golden.py [--reference /root/reference]
 
-The reference's test/data/mel-filter-8x8.csv is copied verbatim (it is data); for mel-spectrogram.csv
-(2.2 MB, input WAV not shipped by the reference) only shape/min/max/mean/std and a 4x8 corner are kept."""
-import argparse, dataclasses, json, os, sys
+The reference's two test fixtures are data and are copied verbatim: test/data/mel-filter-8x8.csv and
+test/data/mel-spectrogram.csv (the expected log-mel of a real speech clip, 80 x 1100; its input WAV is not shipped by the
+reference, so it is used as INPUT to the encoder / decoder / transcribe parity tests, tests/test_gpu_real_speech.py).
+Decode cases store, besides the oracle's per-step trace, each row's 12 best (id, log-prob) of the filtered distribution
+of every step, so that a near-tie split of the fp16 device path can be priced in the oracle's own scores without
+running the oracle (tests/parity.py)."""
+import argparse, dataclasses, json, os, shutil, sys
 import numpy as np
 import torch
 
@@ -27,6 +31,7 @@ torch.set_num_threads(8)
 # 1. reference fixtures
 ref_csv = os.path.join(args.reference, "test/data/mel-spectrogram.csv")
 if os.path.exists(ref_csv):
+    shutil.copyfile(ref_csv, os.path.join(G, "mel-spectrogram.csv"))
     m = np.loadtxt(ref_csv, delimiter=",", dtype=np.float64)
     json.dump({"source": "reference test/data/mel-spectrogram.csv (expected output of test_mel_spectrogram, audio.rs:281-301)",
                "shape": list(m.shape), "min": m.min(), "max": m.max(), "mean": m.mean(), "std": m.std(),
@@ -55,13 +60,18 @@ def run_case(name, dims_name, n_audio, opts, prompt=None, **wkw):
     t = OD.DecodeTask(m, oracle_ids(MODEL_DIMS[dims_name].n_vocab), oracle_decode_options(**opts))
     if prompt is not None:
         t.set_prompt(torch.tensor(prompt, dtype=torch.int64))
+    t.logits_trace = []
     outs = t.run_batch(torch.from_numpy(mel_windows(n_audio)))
     tr = t.extractor.trace
+    top = [lg.log_softmax(-1, dtype=torch.float32).topk(12, dim=-1) for lg in t.logits_trace]
     cases[name] = {"dims": dims_name, "n_audio": n_audio, "options": {k: v for k, v in opts.items()}, "prompt": prompt, "weights_kw": wkw,
                    "tokens": [o.tokens.tolist() for o in outs], "sum_logprob": [o.sum_logprob for o in outs],
                    "avg_logprob": [o.avg_logprob for o in outs], "no_speech_prob": [o.no_speech_prob for o in outs],
                    "n_steps": len(tr), "trace_tokens": [x[0].tolist() for x in tr], "trace_sources": [x[1].tolist() for x in tr],
-                   "trace_sum_logprobs": [[round(float(v), 5) for v in x[2]] for x in tr]}
+                   "trace_sum_logprobs": [[float(v) for v in x[2]] for x in tr],
+                   "initial_tokens": t.prompt_ref[0].initial_tokens.tolist(),
+                   "cand_ids": [tp.indices.tolist() for tp in top],
+                   "cand_lp": [[[None if v == float("-inf") else round(float(v), 6) for v in row] for row in tp.values.tolist()] for tp in top]}
 run_case("nano_beam5", "nano", 1, dict(sample_len=16, beam_size=5))
 run_case("micro_beam5_x2", "micro", 2, dict(sample_len=24, beam_size=5))
 run_case("micro_greedy_x2", "micro", 2, dict(sample_len=20, beam_size=None))

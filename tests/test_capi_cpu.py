@@ -13,8 +13,8 @@ from whisper_rs_amd import _lib as L
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "wrs.h")).read()
+def _declared_symbols(header="wrs.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(wrs_[a-z0-9_]+)\s*\(", txt)))
 
@@ -26,6 +26,18 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in include/wrs.h but not exported by libwrs_mi355x.so"
     assert set(L.SYMBOLS) == set(names), set(L.SYMBOLS) ^ set(names)
+
+
+def test_library_exports_every_debug_symbol():
+    """include/wrs_debug.h (test hooks, not part of the boundary) is held to the same rule."""
+    from whisper_rs_amd import debug as DBG
+    lib = DBG.lib()
+    names = _declared_symbols("wrs_debug.h")
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/wrs_debug.h but not exported by libwrs_mi355x.so"
+    assert set(DBG.SYMBOLS) == set(names), set(DBG.SYMBOLS) ^ set(names)
+    assert not (set(names) & set(_declared_symbols())), "a debug hook leaked into the boundary header"
 
 
 def test_version_and_device_count():

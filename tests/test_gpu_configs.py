@@ -10,34 +10,84 @@
 
 The oracle's language detection and sot-sequence handling follow OpenAI whisper (the reference declares
 Task::LanguageId but does not implement it): parity unpinned by the reference for config 4."""
+import os
+import wave
+
 import numpy as np
 import pytest
 import torch
 
+import parity as P
 from helpers import gpu_model, oracle_model, oracle_ids, oracle_decode_options, mel_windows
-from test_gpu_decode import _oracle_run, _compare, _teacher_forced_check, LP_TOL
+from test_gpu_decode import _oracle_run, _free_run, _teacher_forced_check, LP_TOL
 from whisper_rs_amd import synth
 from whisper_rs_amd.consts import MODEL_DIMS, TokenIds, NON_SPEECH_TOKENS
-from oracle import decode as OD
+from oracle import decode as OD, transcribe as OT
 
 pytestmark = pytest.mark.gpu
+
+
+def test_config1_tiny_en_greedy_wav_file(gpu, tmp_path):
+    """BASELINE config 1: the reference example's flow (examples/transcribe.rs:19-71) with tiny.en dims and greedy
+    selection on ONE 30-s 16 kHz WAV file: file -> load_audio -> TranscribeTask::run (log-mel, encoder, decode loop,
+    segments), against the oracle's TranscribeTask on the very samples the loader returned."""
+    audio = synth.make_audio(1, seed=4242)[0]
+    path = tmp_path / "window.wav"
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(np.clip(np.round(audio * 32767), -32768, 32767).astype("<i2").tobytes())
+    samples = gpu.audio.load_audio(path)                       # audio::load_audio (audio.rs:20-173)
+    assert samples.shape == (480000,) and samples.dtype == np.float32
+    np.testing.assert_allclose(samples, np.clip(np.round(audio * 32767), -32768, 32767) / 32768.0, atol=1e-7)
+    sample_len = 64
+    ot = OT.TranscribeTask(oracle_model("tiny.en"), oracle_ids(), oracle_decode_options(sample_len=sample_len, beam_size=None), None, True)
+    want = ot.run(torch.from_numpy(samples))
+    gt = gpu.TranscribeTask(gpu_model(gpu, "tiny.en"), gpu.TranscribeOptions(
+        decode=gpu.DecodeOptions(sample_len=sample_len, token_extract_mode=gpu.TokenExtractMode.Greedy()),
+        prompt=gpu.TranscribePrompt.None_(True)))               # examples/transcribe.rs:58-60
+    got = gt.run(samples)
+    gt.close()
+    assert [w_[0] for w_ in got.windows] == [w_[0] for w_ in want.windows], "seek sequence differs"
+    if not np.array_equal(got.tokens, want.tokens.numpy()):
+        # greedy argmax near-tie: show it with the window-level machinery (margin recorded), then require equality after resync
+        from oracle import audio as OA
+        mel = OA.log_mel_spectrogram(torch.from_numpy(samples), OA.mel_filter()).numpy()[None]
+        view, _ = _oracle_run("tiny.en", mel, oracle_decode_options(sample_len=sample_len, beam_size=None))
+        task = gpu.DecodeTask(gpu_model(gpu, "tiny.en"), TokenIds.english(), gpu.DecodeOptions(sample_len=sample_len, token_extract_mode=gpu.TokenExtractMode.Greedy()))
+        splits = _free_run("config1_tiny_en_greedy", task, mel, view, 1)
+        task.close()
+        assert splits, "transcribe tokens differ from the oracle but the window decode shows no near-tie"
+    else:
+        assert len(got.segments) == len(want.segments)
+        for g, o in zip(got.segments, want.segments):
+            assert (g.seek, g.start_token, g.end_token) == (o.seek, o.start_token, o.end_token)
+            assert abs(g.start_time - o.start_time) < 1e-9 and abs(g.end_time - o.end_time) < 1e-9
+    print(f"config 1: {len(got.tokens)} tokens, {len(got.segments)} segments, windows {[w_[0] for w_ in got.windows]}")
 
 
 def test_config2_tiny_en_greedy_batch32(gpu):
     n = 32
     mel = mel_windows(n)
-    oouts, otrace = _oracle_run("tiny.en", mel, oracle_decode_options(sample_len=12, beam_size=None))
+    view, _ = _oracle_run("tiny.en", mel, oracle_decode_options(sample_len=64, beam_size=None))
     gm = gpu_model(gpu, "tiny.en")
-    task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=12, max_audio=n, token_extract_mode=gpu.TokenExtractMode.Greedy()))
-    gouts = task.run(mel)
-    split = _compare(gouts, task.trace(), oouts, otrace, 1)
-    print("config 2: steps", task.n_steps, "split", split)
+    task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=64, max_audio=n, token_extract_mode=gpu.TokenExtractMode.Greedy()))
+    splits = _free_run("config2_tiny_en_greedy_x32", task, mel, view, 1)
+    print("config 2: steps", task.n_steps, "near-tie splits", len(splits))
     task.close()
 
 
 def test_config3_base_en_beam5_timestamps_batch16(gpu):
-    exact, steps = _teacher_forced_check(gpu, "base.en", 16, 12, 0.75)
+    exact, steps = _teacher_forced_check(gpu, "base.en", 16, 64, 0.9)
     print(f"config 3: {exact}/{steps} selections reproduced exactly")
+
+
+def test_config3_base_en_beam5_free_running(gpu):
+    """the same configuration free-running on 4 windows (every split explained and re-synchronised)."""
+    mel = mel_windows(4)
+    view, _ = _oracle_run("base.en", mel, oracle_decode_options(sample_len=64, beam_size=5))
+    task = gpu.DecodeTask(gpu_model(gpu, "base.en"), TokenIds.english(), gpu.DecodeOptions(sample_len=64, max_audio=4))
+    _free_run("config3_base_en_beam5_x4", task, mel, view, 5)
+    task.close()
 
 
 def test_config4_multilingual_language_detection_and_decode(gpu):
@@ -48,10 +98,11 @@ def test_config4_multilingual_language_detection_and_decode(gpu):
     mel = mel_windows(n)
     om = oracle_model(dims_name)
     oids = oracle_ids(MODEL_DIMS[dims_name].n_vocab)
-    ot = OD.DecodeTask(om, oids, oracle_decode_options(sample_len=10, beam_size=5, sot_sequence_tail=(first_lang, ids.transcribe)))
+    oopts = oracle_decode_options(sample_len=64, beam_size=5, sot_sequence_tail=(first_lang, ids.transcribe))
+    ot = OD.DecodeTask(om, oids, oopts)
     want_lang, want_probs = ot.detect_language(torch.from_numpy(mel), first_lang, n_lang)
     gm = gpu_model(gpu, dims_name)
-    task = gpu.DecodeTask(gm, ids, gpu.DecodeOptions(sample_len=10, max_audio=n, sot_sequence_tail=[first_lang, ids.transcribe]))
+    task = gpu.DecodeTask(gm, ids, gpu.DecodeOptions(sample_len=64, max_audio=n, sot_sequence_tail=[first_lang, ids.transcribe]))
     got_lang, got_probs = task.detect_language(mel, first_lang, n_lang)
     np.testing.assert_allclose(got_probs.sum(axis=1), 1.0, atol=1e-5)
     np.testing.assert_allclose(got_probs, want_probs.numpy(), atol=2e-3)
@@ -59,30 +110,26 @@ def test_config4_multilingual_language_detection_and_decode(gpu):
     for a in range(n):  # ids must agree unless the oracle's two best languages are closer than the fp16 noise
         if top2[a, 1] - top2[a, 0] > 4e-3:
             assert got_lang[a] == int(want_lang[a])
-    # decode with per-window language tokens; windows reuse the encoder output of the detection call
+    # decode with per-window language tokens
     langs = [int(x) for x in want_lang]
-    ot.languages = langs
-    oouts = ot.run_batch(torch.from_numpy(mel))
-    tr = ot.extractor.trace
-    otrace = (np.stack([t[0].numpy() for t in tr]), np.stack([t[1].numpy() for t in tr]), np.stack([t[2].numpy() for t in tr]))
+    view, _ = _oracle_run(dims_name, mel, oopts, languages=langs)
     task.set_languages(langs)
-    gouts = task.run_encoded(n)
-    _compare(gouts, task.trace(), oouts, otrace, 5)
-    # same through the mel entry, and with no per-window override the tail's own language token is used
-    g2 = task.run(mel)
-    for a, b in zip(gouts, g2):
+    _free_run("config4_micro_ml_langs", task, mel, view, 5)
+    # windows whose encoder output is still resident decode the same through run_encoded as through the mel entry
+    g1 = task.run(mel)
+    g2 = task.run_encoded(n)
+    for a, b in zip(g1, g2):
         np.testing.assert_array_equal(a.tokens, b.tokens)
+    # with no per-window override the tail's own language token is used
     task.set_languages(None)
-    ot.languages = None
-    oouts = ot.run_batch(torch.from_numpy(mel))
-    tr = ot.extractor.trace
-    otrace = (np.stack([t[0].numpy() for t in tr]), np.stack([t[1].numpy() for t in tr]), np.stack([t[2].numpy() for t in tr]))
-    _compare(task.run(mel), task.trace(), oouts, otrace, 5)
+    view, _ = _oracle_run(dims_name, mel, oopts, languages=None)
+    _free_run("config4_micro_ml_default_lang", task, mel, view, 5)
     task.close()
 
 
-def test_config4_small_dims_language_detection(gpu):
-    """the real `small` shape (D 768, 12 heads, 12 layers, V 51865) on 2 windows: detection probabilities vs the oracle."""
+def test_config4_small_dims_language_detection_and_decode(gpu):
+    """the real `small` shape (D 768, 12 heads, 12 layers, V 51865) on 2 windows: detection probabilities vs the oracle,
+    then 64 teacher-forced beam-5 steps with the [sot, lang, transcribe] prompt."""
     dims_name = "small"
     ids = TokenIds.multilingual()
     first_lang = ids.sot + 1
@@ -93,6 +140,9 @@ def test_config4_small_dims_language_detection(gpu):
     got_lang, got_probs = task.detect_language(mel, first_lang, 99)
     np.testing.assert_allclose(got_probs, want_probs.numpy(), atol=3e-3)
     task.close()
+    tail = (first_lang + 3, ids.transcribe)
+    exact, steps = _teacher_forced_check(gpu, dims_name, 2, 64, 0.9, ids=ids, okw=dict(sot_sequence_tail=tail), gkw=dict(sot_sequence_tail=list(tail)))
+    print(f"config 4 (small dims): {exact}/{steps} selections reproduced exactly")
 
 
 # ------------------------------------------------------------------------------------------------ config 5

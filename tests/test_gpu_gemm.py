@@ -1,0 +1,302 @@
+"""GPU parity of every GEMM kernel variant of the hot path AT THE SHAPES bench.py RUNS THEM (large-v2: D 1280, 4D 5120,
+3D 3840, vocabulary 51865 padded to 51872, 256 windows -> 384 000 encoder rows / 1280 decoder rows), through the library's
+own weight packer and launchers (wrs_debug_gemm_f16, include/wrs_debug.h).
+
+Reference: torch fp32 matmul on the SAME fp16-rounded inputs (an independent implementation: rocBLAS), plus the
+epilogue in torch.  These kernels replace the `nn::Linear` / `conv1d` call sites of reference src/model.rs:158-206,
+279-292,417-441,490-522.  Tolerances (written out below): fp32 outputs 1e-4 of the output scale (accumulation order
+only), fp16 outputs 1.5e-3 of the output scale (one fp16 rounding).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from whisper_rs_amd import debug as DBG
+from whisper_rs_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+D = 1280
+TOL_F32 = 1e-4   # |c - ref|.max() / |ref|.max(), fp32 output
+TOL_F16 = 1.5e-3  # fp16 output (half-ulp of fp16 is 4.9e-4 relative)
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device=_dev())
+    g.manual_seed(seed)
+    return (scale * torch.randn(shape, generator=g, device=_dev(), dtype=torch.float32)).to(torch.float16)
+
+
+def _gelu(x):
+    return torch.nn.functional.gelu(x, approximate="none")
+
+
+def _run(g):
+    torch.cuda.synchronize()
+    L.check(DBG.lib().wrs_debug_gemm_f16(C.byref(g)))
+    return g.kernel_used
+
+
+def _rel_err(got, ref):
+    return float((got - ref).abs().max() / ref.abs().max())
+
+
+def _tiled(a16, w32, M, N, K, *, force=DBG.GEMM_AUTO, packed=False, bias=None, scale=1.0, scale_n_end=0, act=0, residual=None,
+           posemb=None, c_f32=True, c_packed=False, ldc=None, ksplit=1, n_w=None, c_rows=None, a_desc=None, c_desc=None, conv_c=0):
+    """one launch through wrs_debug_gemm_f16; returns (C as fp32 [c_rows, ldc] or slabs, kernel id)."""
+    dev = _dev()
+    g = DBG.DebugGemmC()
+    g.device_id, g.path, g.force_kernel = 0, DBG.PATH_TILED, force
+    g.M, g.N, g.K = M, N, K
+    keep = []
+    if packed:
+        rows_pad = -(-M // 128) * 128
+        ap = DBG.pack_activations(a16, rows_pad)
+        keep.append(ap)
+        g.a, g.a_packed, g.packed_rows = ap.data_ptr(), 1, rows_pad
+    else:
+        g.a, g.a_packed = a16.data_ptr(), 0
+        if a_desc:
+            g.lda, g.rows_per_batch, g.batch_stride = a_desc
+        else:
+            g.lda = K
+    g.w, g.n_w, g.k_w, g.conv_c = w32.data_ptr(), (n_w or N), (3 * conv_c if conv_c else w32.shape[1]), conv_c
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.scale, g.scale_n_end, g.act = scale, scale_n_end, act
+    g.posemb = posemb.data_ptr() if posemb is not None else None
+    ldc = ldc or N
+    c_rows = c_rows or M
+    if ksplit > 1:
+        out = torch.zeros(ksplit, c_rows, ldc, dtype=torch.float32, device=dev)
+        g.slab_stride = c_rows * ldc
+    elif c_packed:
+        out = torch.zeros((-(-M // 128) * 128) * N, dtype=torch.float16, device=dev)
+    else:
+        out = torch.zeros(c_rows, ldc, dtype=torch.float32 if c_f32 else torch.float16, device=dev)
+    if residual is not None:  # the model aliases residual and C (x += ...): do the same
+        out.copy_(residual)
+        g.residual = out.data_ptr()
+    g.c, g.c_f32, g.c_packed, g.ldc, g.ksplit = out.data_ptr(), int(c_f32), int(c_packed), ldc, ksplit
+    if c_desc:
+        g.c_rows_per_batch, g.c_batch_rows, g.c_row_off = c_desc
+    used = _run(g)
+    if c_packed:
+        out = DBG.unpack_activations(out, M, N)
+    return out.float(), used
+
+
+def _ref(a16, w32, bias=None, scale=1.0, scale_n_end=0, act=0, residual=None, posemb=None):
+    r = a16.float() @ w32.t()
+    if bias is not None:
+        r = r + bias
+    if scale_n_end:
+        r[:, :scale_n_end] *= scale
+    if act:
+        r = _gelu(r)
+    if posemb is not None:
+        r = r + posemb
+    if residual is not None:
+        r = r + residual
+    return r
+
+
+# ------------------------------------------------------------------------------------------------ encoder shapes
+# (name, N, K, epilogue) of the encoder / cross-K/V GEMMs of large-v2 (model.cpp::encoder_from_mel_t, load_cross_kv)
+ENC_SHAPES = [
+    ("qkv", 3 * D, D, dict(bias=True, scale=True, f16=True)),
+    ("attn_out", D, D, dict(bias=True, residual=True)),
+    ("mlp1", 4 * D, D, dict(bias=True, act=True, f16=True)),
+    ("mlp2", D, 4 * D, dict(bias=True, residual=True)),
+    ("cross_kv", 2 * D, D, dict(bias=True, scale=True, f16=True)),
+]
+
+
+@pytest.mark.parametrize("force", [DBG.GEMM_AUTO, DBG.GEMM_PP2, DBG.GEMM_TILE128], ids=["auto", "pp2", "tile128"])
+@pytest.mark.parametrize("name,N,K,epi", ENC_SHAPES, ids=[s[0] for s in ENC_SHAPES])
+@pytest.mark.parametrize("M", [12000, 1280])
+def test_encoder_gemm_shapes(gpu, M, name, N, K, epi, force):
+    """row-major A.  M = 12 000 = 8 windows x 1500 (not a multiple of 128 or 256: edge tiles), M = 1280."""
+    a = _rand((M, K), 1)
+    w = _rand((N, K), 2, K ** -0.5).float()
+    bias = _rand((N,), 3, 0.1).float() if epi.get("bias") else None
+    res = _rand((M, N), 4).float() if epi.get("residual") else None
+    scale, sne = (64 ** -0.25, (2 * D if N == 3 * D else D)) if epi.get("scale") else (1.0, 0)
+    got, used = _tiled(a, w, M, N, K, force=force, bias=bias, scale=scale, scale_n_end=sne, act=int(bool(epi.get("act"))),
+                       residual=res, c_f32=not epi.get("f16"))
+    ref = _ref(a, w, bias, scale, sne, epi.get("act"), res)
+    err = _rel_err(got, ref)
+    print(f"enc {name} M={M} N={N} K={K} kernel={DBG.GEMM_NAMES[used]} rel_err={err:.2e}")
+    if force != DBG.GEMM_AUTO:
+        assert used == force
+    assert err < (TOL_F16 if epi.get("f16") else TOL_F32)
+
+
+def test_encoder_gemm_full_bench_rows(gpu):
+    """M = 384 000 = 256 windows x 1500 rows, the row count of the benchmark pass (attn_out shape: bias + residual, fp32)."""
+    M, N, K = 384000, D, D
+    a = _rand((M, K), 11)
+    w = _rand((N, K), 12, K ** -0.5).float()
+    bias = _rand((N,), 13, 0.1).float()
+    res = _rand((M, N), 14).float()
+    got, used = _tiled(a, w, M, N, K, bias=bias, residual=res)
+    assert used == DBG.GEMM_PP2, "the benchmark runs this shape on the 256x256 ping-pong kernel"
+    ref = _ref(a, w, bias, residual=res)
+    err = _rel_err(got, ref)
+    print(f"enc attn_out M={M}: rel_err={err:.2e}")
+    assert err < TOL_F32
+    del got, ref, res
+    # mlp1 at the same row count on a 64 000-row slice of distinct data placed at the END of a 384 000-row problem is
+    # equivalent to the tile walk of the last bands; run the full mlp1 shape at 64 000 rows (fp16 + GELU epilogue)
+    M2 = 64000
+    w1 = _rand((4 * D, D), 15, D ** -0.5).float()
+    b1 = _rand((4 * D,), 16, 0.1).float()
+    got, used = _tiled(a[:M2], w1, M2, 4 * D, D, bias=b1, act=1, c_f32=False)
+    assert used == DBG.GEMM_PP2
+    err = _rel_err(got, _ref(a[:M2], w1, b1, act=1))
+    print(f"enc mlp1 M={M2}: rel_err={err:.2e}")
+    assert err < TOL_F16
+
+
+@pytest.mark.parametrize("force", [DBG.GEMM_AUTO, DBG.GEMM_TILE128], ids=["auto", "tile128"])
+def test_conv_as_gemm_overlapping_rows(gpu, force):
+    """conv1 (k3, pad 1) and conv2 (k3, stride 2, pad 1) as implicit GEMMs over overlapping rows of a zero-padded
+    time-major activation (reference model.rs:421-431), at D = 1280, 4 windows, vs torch conv1d."""
+    nb, Tm, T = 4, 3000, 1500
+    g = torch.Generator(device=_dev())
+    g.manual_seed(5)
+    mel = torch.randn(nb, 80, Tm, generator=g, device=_dev()).to(torch.float16)
+    w1 = _rand((D, 80, 3), 6, 240 ** -0.5).float()
+    b1 = _rand((D,), 7, 0.1).float()
+    # A = [nb, 3002, 80] time-major with one zero row each side (launch_mel_prep's layout)
+    a = torch.zeros(nb, 3002, 80, dtype=torch.float16, device=_dev())
+    a[:, 1:3001] = mel.permute(0, 2, 1)
+    a = torch.cat([a.flatten(), torch.zeros(256, dtype=torch.float16, device=_dev())])
+    # c1 = [nb, 3001, D] fp16, row 0 of every window stays zero (conv2's left padding)
+    got, used = _tiled(a, w1.flatten(1), nb * Tm, D, 256, force=force, bias=b1, act=1, c_f32=False, n_w=D, conv_c=80,
+                       a_desc=(80, Tm, 3002 * 80), c_rows=nb * 3001, c_desc=(Tm, 3001, 1))
+    ref1 = _gelu(torch.nn.functional.conv1d(mel.float(), w1, b1, padding=1))          # [nb, D, 3000]
+    c1 = got.view(nb, 3001, D)
+    assert float(c1[:, 0].abs().max()) == 0.0
+    err = _rel_err(c1[:, 1:], ref1.permute(0, 2, 1))
+    print(f"conv1 kernel={DBG.GEMM_NAMES[used]} rel_err={err:.2e}")
+    assert err < TOL_F16
+    # conv2 on the fp16 c1 the library produced: rows overlap (lda = 2D < K = 3D)
+    c1h = torch.cat([got.to(torch.float16).flatten(), torch.zeros(4 * D, dtype=torch.float16, device=_dev())])
+    w2 = _rand((D, D, 3), 8, (3 * D) ** -0.5).float()
+    b2 = _rand((D,), 9, 0.1).float()
+    pos = _rand((T, D), 10).float()
+    got2, used2 = _tiled(c1h, w2.flatten(1), nb * T, D, 3 * D, force=force, bias=b2, act=1, posemb=pos, n_w=D, conv_c=D,
+                         a_desc=(2 * D, T, 3001 * D), c_desc=(T, T, 0))
+    x1 = c1[:, 1:].to(torch.float16).float().permute(0, 2, 1)                          # [nb, D, 3000] as stored
+    ref2 = _gelu(torch.nn.functional.conv1d(x1, w2, b2, stride=2, padding=1)).permute(0, 2, 1) + pos
+    err2 = _rel_err(got2.view(nb, T, D), ref2)
+    print(f"conv2 kernel={DBG.GEMM_NAMES[used2]} rel_err={err2:.2e}")
+    assert err2 < TOL_F32
+
+
+# ------------------------------------------------------------------------------------------------ decode-step shapes
+def _dec_split(M, N, K):
+    """the split-K factor Model::decoder_step picks for the slab GEMMs at >= 480 rows (model.cpp gemm_slab)."""
+    tiles = -(-M // 128) * -(-N // 128)
+    split = 1
+    while tiles * split * 2 <= 256 and (K // 64) % (split * 2) == 0 and K // 64 // (split * 2) >= 10:
+        split *= 2
+    return split
+
+
+DEC_SHAPES = [("qkv", 3 * D, D), ("attn_out", D, D), ("mlp2", D, 4 * D)]
+
+
+@pytest.mark.parametrize("force", [DBG.GEMM_AUTO, DBG.GEMM_TILE128_PACKED, DBG.GEMM_RING], ids=["auto", "tile128p", "ring"])
+@pytest.mark.parametrize("name,N,K", DEC_SHAPES, ids=[s[0] for s in DEC_SHAPES])
+@pytest.mark.parametrize("M", [1280, 500])
+def test_decode_step_slab_gemms(gpu, M, name, N, K, force):
+    """packed activations, fp32 slabs, the split-K the decode step uses (2 for the N = D shapes at 1280 rows: the
+    LDS-transposed slab store) and split 1; 1280 rows = 256 windows x beam 5, 500 rows = edge row tile."""
+    a = _rand((M, K), 21)
+    w = _rand((N, K), 22, K ** -0.5).float()
+    ref = a.float() @ w.t()
+    for ksplit in sorted({1, _dec_split(M, N, K), 2}):
+        got, used = _tiled(a, w, M, N, K, force=force, packed=True, ksplit=ksplit)
+        if ksplit > 1:
+            got = got.sum(0)
+        err = _rel_err(got, ref)
+        print(f"dec {name} M={M} N={N} K={K} ksplit={ksplit} kernel={DBG.GEMM_NAMES[used]} rel_err={err:.2e}")
+        if force != DBG.GEMM_AUTO:
+            assert used == force
+        elif M == 1280 and N == D and ksplit == 2:
+            assert used == DBG.GEMM_RING, "the benchmark runs the N = D decode GEMMs on the ring kernel"
+        assert err < TOL_F32
+
+
+@pytest.mark.parametrize("force", [DBG.GEMM_AUTO, DBG.GEMM_RING], ids=["auto", "ring"])
+@pytest.mark.parametrize("M", [1280, 500])
+def test_decode_step_mlp1_packed_gelu(gpu, M, force):
+    """MLP-1 of the decode step at >= 480 rows: bias + exact GELU + fp16 store in packed-activation order."""
+    N, K = 4 * D, D
+    a = _rand((M, K), 31)
+    w = _rand((N, K), 32, K ** -0.5).float()
+    bias = _rand((N,), 33, 0.1).float()
+    got, used = _tiled(a, w, M, N, K, force=force, packed=True, bias=bias, act=1, c_f32=False, c_packed=True, ldc=N)
+    err = _rel_err(got, _ref(a, w, bias, act=1))
+    print(f"dec mlp1 M={M} kernel={DBG.GEMM_NAMES[used]} rel_err={err:.2e}")
+    assert err < TOL_F16
+
+
+@pytest.mark.parametrize("M", [1280, 500])
+def test_decode_step_logits_gemm(gpu, M):
+    """tied output projection (reference model.rs:521) at >= 480 rows: V = 51865 weight rows, logits row pitch 51872."""
+    V, ld, K = 51865, 51872, D
+    a = _rand((M, K), 41)
+    w = _rand((V, K), 42, 1.5 * K ** -0.5).float()
+    got, used = _tiled(a, w, M, ld, K, packed=True, ldc=ld, n_w=V)
+    assert used == DBG.GEMM_TILE128_PACKED
+    ref = a.float() @ w.t()
+    err = _rel_err(got[:, :V], ref)
+    print(f"dec logits M={M} rel_err={err:.2e}")
+    assert err < TOL_F32
+    assert float(got[:, V:].abs().max()) == 0.0  # padded columns come from zero weight rows
+
+
+@pytest.mark.parametrize("M", [5, 40, 160, 320, 475])
+def test_decode_step_small_row_paths(gpu, M):
+    """fewer than 480 rows: the latency-optimised split-K decode GEMM (every shape of a layer) and the skinny fp32
+    GEMM of the logits."""
+    for name, N, K in DEC_SHAPES + [("mlp1", 4 * D, D)]:
+        a = _rand((M, K), 51)
+        w = _rand((N, K), 52, K ** -0.5).float()
+        rows_pad = max(-(-M // 128) * 128, 640)
+        ap = DBG.pack_activations(a, rows_pad)
+        slab = torch.zeros(16 * 640 * N, dtype=torch.float32, device=_dev())  # <= 10 slabs x m_pad <= 480 rows x N
+        g = DBG.DebugGemmC()
+        g.device_id, g.path, g.M, g.N, g.K = 0, DBG.PATH_DEC, M, N, K
+        g.a, g.a_packed, g.packed_rows = ap.data_ptr(), 1, rows_pad
+        g.w, g.n_w, g.k_w = w.data_ptr(), N, K
+        g.c, g.c_f32, g.ldc = slab.data_ptr(), 1, N
+        _run(g)
+        m_pad = g.slab_stride // N
+        got = slab[: g.ksplit * g.slab_stride].view(g.ksplit, m_pad, N).sum(0)[:M]
+        err = _rel_err(got, a.float() @ w.t())
+        print(f"dec(small) {name} M={M} N={N} K={K} slabs={g.ksplit} rel_err={err:.2e}")
+        assert err < TOL_F32
+    V, ld, K = 51865, 51872, D
+    a = _rand((M, K), 61)
+    w = _rand((V, K), 62, 1.5 * K ** -0.5).float()
+    rows_pad = -(-M // 128) * 128
+    ap = DBG.pack_activations(a, max(rows_pad, 640))
+    out = torch.zeros(M, ld, dtype=torch.float32, device=_dev())
+    g = DBG.DebugGemmC()
+    g.device_id, g.path, g.M, g.N, g.K = 0, DBG.PATH_SKINNY_F32, M, V, K
+    g.a, g.a_packed, g.packed_rows = ap.data_ptr(), 1, max(rows_pad, 640)
+    g.w, g.n_w, g.k_w = w.data_ptr(), V, K
+    g.c, g.c_f32, g.ldc = out.data_ptr(), 1, ld
+    _run(g)
+    err = _rel_err(out[:, :V], a.float() @ w.t())
+    print(f"dec(small) logits M={M} rel_err={err:.2e}")
+    assert err < TOL_F32

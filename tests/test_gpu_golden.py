@@ -9,8 +9,9 @@ import numpy as np
 import pytest
 import torch
 
+import parity as P
 from helpers import gpu_model, mel_windows
-from test_gpu_decode import _compare
+from whisper_rs_amd.consts import MODEL_DIMS
 from whisper_rs_amd import synth
 from whisper_rs_amd.consts import TokenIds
 
@@ -46,11 +47,8 @@ def test_decode_vs_golden(gpu, name):
                                                                     timestamps=o.get("timestamps", True), max_audio=c["n_audio"]))
     if c["prompt"] is not None:
         task.set_prompt(c["prompt"])
-    gouts = task.run(mel_windows(c["n_audio"]))
-    oouts = [SimpleNamespace(tokens=torch.tensor(t), sum_logprob=s, avg_logprob=a, no_speech_prob=n)
-             for t, s, a, n in zip(c["tokens"], c["sum_logprob"], c["avg_logprob"], c["no_speech_prob"])]
-    otrace = (np.array(c["trace_tokens"]), np.array(c["trace_sources"]), np.array(c["trace_sum_logprobs"], dtype=np.float32))
     group = 1 if o.get("beam_size", 5) is None else o.get("beam_size", 5)
-    split = _compare(gouts, task.trace(), oouts, otrace, group)
-    print(f"{name}: steps {task.n_steps}, split {split}")
+    view = P.OracleView.from_golden(c, MODEL_DIMS[c["dims"]].n_vocab, c["initial_tokens"])
+    splits = P.run_with_resync("golden_" + name, task, mel_windows(c["n_audio"]), view, group, TokenIds.english().eot)
+    print(f"{name}: steps {task.n_steps}, explained splits {len(splits)}")
     task.close()

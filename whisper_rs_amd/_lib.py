@@ -61,7 +61,8 @@ class SegmentC(C.Structure):
 class TranscribeOutputC(C.Structure):
     _fields_ = [("tokens", C.POINTER(C.c_int64)), ("n_tokens", C.c_int64), ("segments", C.POINTER(SegmentC)),
                 ("n_segments", C.c_int64), ("window_seek", C.POINTER(C.c_int64)), ("window_avg_logprob", C.POINTER(C.c_double)),
-                ("window_no_speech_prob", C.POINTER(C.c_double)), ("n_windows", C.c_int64), ("text", C.c_void_p)]
+                ("window_no_speech_prob", C.POINTER(C.c_double)), ("n_windows", C.c_int64), ("text", C.c_void_p),
+                ("truncated", C.c_int32)]
 
 
 class StageTimeC(C.Structure):
@@ -126,6 +127,7 @@ SYMBOLS = {
     "wrs_window_pool_destroy": (None, [C.c_void_p]),
     "wrs_transcribe_task_create": (C.c_int, [C.c_void_p, P(TokenIdsC), P(TranscribeOptionsC), P(C.c_void_p)]),
     "wrs_transcribe_task_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, P(TranscribeOutputC)]),
+    "wrs_transcribe_task_run_mel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, P(TranscribeOutputC)]),
     "wrs_transcribe_task_run_chunked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, P(TranscribeOutputC)]),
     "wrs_transcribe_output_free": (None, [P(TranscribeOutputC)]),
     "wrs_transcribe_task_destroy": (None, [C.c_void_p]),

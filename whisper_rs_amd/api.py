@@ -607,6 +607,7 @@ class TranscribeOutput:
     segments: List[TranscribeOutputSegment]
     windows: list  # (seek, avg_logprob, no_speech_prob)
     text: Optional[str] = None
+    truncated: bool = False  # the loop stopped before the end of the audio (zero seek advance / window limit)
 
 
 class TranscribeTask:
@@ -639,13 +640,22 @@ class TranscribeTask:
                 for s in (out.segments[i] for i in range(out.n_segments))]
         wins = [(out.window_seek[i], out.window_avg_logprob[i], out.window_no_speech_prob[i]) for i in range(out.n_windows)]
         text = _take_text(out.text)
+        truncated = bool(out.truncated)
         self._lib.wrs_transcribe_output_free(C.byref(out))
-        return TranscribeOutput(toks, segs, wins, text)
+        return TranscribeOutput(toks, segs, wins, text, truncated)
 
     def run(self, audio_: np.ndarray) -> TranscribeOutput:
         a = _f32(audio_)
         out = L.TranscribeOutputC()
         L.check(self._lib.wrs_transcribe_task_run(self._h, _ptr(a), a.shape[0], C.byref(out)))
+        return self._collect(out)
+
+    def run_mel(self, mel: np.ndarray) -> TranscribeOutput:
+        """the long-form loop on a log-mel spectrogram [80, n_frames] (run_inner after transcribe.rs:112)."""
+        mel = _f32(mel)
+        assert mel.ndim == 2 and mel.shape[0] == N_MELS
+        out = L.TranscribeOutputC()
+        L.check(self._lib.wrs_transcribe_task_run_mel(self._h, _ptr(mel), mel.shape[1], C.byref(out)))
         return self._collect(out)
 
     def run_chunked(self, audio_: np.ndarray, batch: int) -> TranscribeOutput:

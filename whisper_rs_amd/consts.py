@@ -49,6 +49,9 @@ MODEL_DIMS = {
     "micro": _dims(51864, 128, 2, 2),
     "micro.ml": _dims(51865, 128, 2, 2),  # multilingual vocabulary layout
     "nano": _dims(51864, 64, 1, 1),
+    # large-v2's width, heads and vocabulary with 2 layers: every kernel runs at the benchmark's shapes (D 1280, 20 heads,
+    # 4D 5120, V 51865) while the CPU oracle still finishes in seconds
+    "wide": _dims(51865, 1280, 20, 2),
 }
 
 

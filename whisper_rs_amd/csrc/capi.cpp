@@ -447,6 +447,9 @@ int wrs_transcribe_task_set_prompt_text(wrs_transcribe_task* t, const char* utf8
 int wrs_transcribe_task_run(wrs_transcribe_task* t, const float* audio, int64_t n, wrs_transcribe_output* out) {
     return guarded([&] { WRS_REQUIRE(t, "null task"); t->t.run(audio, n, out); });
 }
+int wrs_transcribe_task_run_mel(wrs_transcribe_task* t, const float* mel, int64_t n_frames, wrs_transcribe_output* out) {
+    return guarded([&] { WRS_REQUIRE(t, "null task"); t->t.run_mel(mel, n_frames, out); });
+}
 int wrs_transcribe_task_run_chunked(wrs_transcribe_task* t, const float* audio, int64_t n, int32_t batch, wrs_transcribe_output* out) {
     return guarded([&] { WRS_REQUIRE(t, "null task"); t->t.run_chunked(audio, n, batch, out); });
 }
@@ -462,58 +465,6 @@ void wrs_transcribe_task_destroy(wrs_transcribe_task* t) {
     if (!t) return;
     (void)hipSetDevice(t->t.m->device);
     delete t;
-}
-
-// ------------------------------------------------------------------ debug hooks (not part of wrs.h)
-// teacher-forced decode of mel [n_audio,80,3000] (host): see DecodeTask::run_forced
-int wrs_debug_decode_forced(wrs_decode_task* t, const float* mel, int n_audio, int n_steps, const int32_t* ftok, const int32_t* fsrc,
-                            float* out_lp, int32_t* out_id, double* out_no_speech) {
-    return guarded([&] {
-        WRS_REQUIRE(t && mel, "null argument");
-        Model& m = *t->t.m;
-        m.use();
-        m.load_mel(mel, n_audio, WRS_MEM_HOST, WRS_N_FRAMES, 0);
-        t->t.run_forced(n_audio, n_steps, ftok, fsrc, out_lp, out_id, out_no_speech);
-    });
-}
-// host sequencer alone (no device needed): see DecodeTask::simulate.  Trace of the run through out_* ([steps][rows]).
-int wrs_debug_sequencer_run(const wrs_token_ids* ids, const wrs_decode_options* opt, const int64_t* initial, int32_t n_initial, int32_t n_audio,
-                            int32_t n_steps, const float* lp, const int32_t* id, wrs_decode_result* out, int32_t* out_tokens,
-                            int32_t* out_sources, float* out_slp) {
-    return guarded([&] {
-        WRS_REQUIRE(ids && opt && out, "null argument");
-        DecodeTask t;
-        t.simulate(*ids, *opt, initial, n_initial, n_audio, n_steps, lp, id, out);
-        const size_t n = t.tr_tokens.size();
-        if (out_tokens) memcpy(out_tokens, t.tr_tokens.data(), n * 4);
-        if (out_sources) memcpy(out_sources, t.tr_src.data(), n * 4);
-        if (out_slp) memcpy(out_slp, t.tr_slp.data(), n * 4);
-    });
-}
-// long-form bookkeeping alone (no device needed): see simulate_transcribe
-int wrs_debug_transcribe_bookkeeping(int32_t ts_begin, int64_t n_audio_ctxs, int64_t n_frames, const int64_t* prompt, int64_t n_prompt,
-                                     const int64_t* window_tokens, const int32_t* window_lens, int32_t n_windows, const wrs_tokenizer* tok,
-                                     wrs_transcribe_output* out) {
-    return guarded([&] {
-        simulate_transcribe(ts_begin, n_audio_ctxs, n_frames, prompt, n_prompt, window_tokens, window_lens, n_windows, tok ? &tok->t : nullptr, out);
-    });
-}
-int wrs_debug_set_encoder_stop(wrs_model* h, int n_launches) { if (h) h->m.debug_enc_stop = n_launches; return 0; }
-// copy an internal encoder workspace buffer to host as f32. which: 0 x(f32) 1 xn 2 qkv 3 att 4 h 5 c1 6 mel_t 7 xa16
-int wrs_debug_read_encoder(wrs_model* h, int which, float* out, int64_t n) {
-    return guarded([&] {
-        Model& m = h->m;
-        m.use();
-        HIP_CHECK(hipStreamSynchronize(m.stream));
-        EncoderWorkspace& w = m.enc_ws;
-        if (which == 0) { HIP_CHECK(hipMemcpy(out, w.x.p, (size_t)n * 4, hipMemcpyDeviceToHost)); return; }
-        const DevBuf* b = which == 1 ? &w.xn : which == 2 ? &w.qkv : which == 3 ? &w.att : which == 4 ? &w.h : which == 5 ? &w.c1 : which == 6 ? &w.mel_t : &w.xa16;
-        DevBuf tmp;
-        tmp.alloc((size_t)n * 4);
-        launch_f16_to_f32(b->as<half_t>(), tmp.as<float>(), n, m.stream);
-        HIP_CHECK(hipStreamSynchronize(m.stream));
-        HIP_CHECK(hipMemcpy(out, tmp.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    });
 }
 
 // ------------------------------------------------------------------ measurement

@@ -134,9 +134,10 @@ void DecodeTask::configure(Model* model, const wrs_token_ids& tid, const wrs_dec
     for (int id : suppress_ids) WRS_REQUIRE(id >= 0 && id < V, "DecodeTask: suppress id %d out of range", id);
     m->use();
     suppress_dev.alloc(std::max<size_t>(suppress_ids.size(), 1) * 4);
-    if (!suppress_ids.empty())
+    if (!suppress_ids.empty()) {
         HIP_CHECK(hipMemcpyAsync(suppress_dev.p, suppress_ids.data(), suppress_ids.size() * 4, hipMemcpyHostToDevice, utility_stream()));
         HIP_CHECK(hipStreamSynchronize(utility_stream()));
+    }
     sot_tail.clear();
     audio_lang.clear();
     for (int i = 0; i < o.n_sot_sequence_tail; ++i) {
@@ -262,6 +263,31 @@ void DecodeTask::step_decode(int R) {
         HIP_CHECK(hipStreamSynchronize(m->stream));
         m->collect_cross_events(R / group);
         m->cross_ev_now = false;
+    }
+}
+
+void DecodeTask::record_candidates(int R, bool step0) {
+    if (!keep_candidates) return;
+    const int k = (mode == WRS_EXTRACT_BEAM_SEARCH) ? group + 1 : 1;
+    for (int r = 0; r < R; ++r) {
+        const int trow = step0 ? r / group : r;  // step 0: one prefill row per audio, shared by its beams
+        for (int c = 0; c < k; ++c) {
+            tr_cand_lp.push_back(st.topk_lp()[trow * k + c]);
+            tr_cand_id.push_back(st.topk_id()[trow * k + c]);
+        }
+    }
+}
+
+// test aid: replace the outcome of step `step` by the given decisions (the finished lists keep what update_* admitted)
+void DecodeTask::apply_forced(int step, const std::vector<std::vector<int64_t>>& old_rows) {
+    const int R = (int)old_rows.size();
+    for (int r = 0; r < R; ++r) {
+        const int src = forced_src[(size_t)step * R + r];
+        WRS_REQUIRE(src >= 0 && src < R, "forced decode: source %d out of range", src);
+        rows[r] = old_rows[src];
+        rows[r].push_back(forced_tok[(size_t)step * R + r]);
+        sources[r] = src;
+        sum_logprobs[r] = forced_slp[(size_t)step * R + r];
     }
 }
 
@@ -409,6 +435,7 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
     finished.assign(n_audio, {});
     no_speech.assign(n_audio, NAN);
     tr_tokens.clear(); tr_src.clear(); tr_slp.clear();
+    tr_cand_lp.clear(); tr_cand_id.clear();
     tr_rows = R;
     n_steps = 0;
 
@@ -441,7 +468,11 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
     t_prefill_ms = now_ms() - tA;
 
     tA = now_ms();
+    record_candidates(R, true);
+    std::vector<std::vector<int64_t>> old_rows;
+    if (forced_n > 0) old_rows = rows;
     bool completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, true, st.topk_lp(), st.topk_id()) : update_greedy(n_audio, true, st.topk_lp(), st.topk_id());
+    if (forced_n > 0) apply_forced(0, old_rows);
     record_trace(R);
     n_steps = 1;
     t_host_ms += now_ms() - tA;
@@ -463,7 +494,10 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
         step_decode(R);
         const double t2 = now_ms();
         if (m->timer && m->timer->enabled) m->timer->collect();
+        record_candidates(R, false);
+        if (i < forced_n) old_rows = rows;
         completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, false, st.topk_lp(), st.topk_id()) : update_greedy(n_audio, false, st.topk_lp(), st.topk_id());
+        if (i < forced_n) apply_forced(i, old_rows);
         record_trace(R);
         n_steps = i + 1;
         t_steps_ms += t2 - t1;
@@ -525,10 +559,10 @@ void DecodeTask::simulate(const wrs_token_ids& tid, const wrs_decode_options& o,
 // candidates the device produced for step s (before that outcome is applied) are returned in out_lp/out_id
 // [n_steps][R][k].  Step 0 candidates come from the per-audio prefill row, replicated over its beams.
 void DecodeTask::run_forced(int n_audio, int n_steps, const int32_t* ftok, const int32_t* fsrc, float* out_lp,
-                            int32_t* out_id, double* out_no_speech) {
+                            int32_t* out_id, double* out_no_speech, bool have_features) {
     WRS_REQUIRE(n_audio >= 1 && n_audio <= max_audio && n_steps >= 1 && ftok && fsrc && out_lp && out_id, "run_forced: bad argument");
     m->use();
-    m->encoder_from_mel_t(n_audio);
+    if (!have_features) m->encoder_from_mel_t(n_audio);
     const int G = group, R = n_audio * G, S = sample_begin;
     const int k = (mode == WRS_EXTRACT_BEAM_SEARCH) ? G + 1 : 1;
     WRS_REQUIRE(S + n_steps - 1 <= m->n_ctx, "run_forced: %d prompt + %d steps exceed n_text_ctxs", S, n_steps);

@@ -56,6 +56,17 @@ struct DecodeTask {
     std::vector<int32_t> tr_tokens, tr_src;
     std::vector<float> tr_slp;
     int tr_rows = 0;
+    // test aids (include/wrs_debug.h): per-step device candidates of the last run, and a forced prefix of beam decisions
+    // (re-synchronisation with the oracle after a near-tie: steps < forced_n take the given tokens / sources / scores)
+    bool keep_candidates = false;
+    std::vector<float> tr_cand_lp;
+    std::vector<int32_t> tr_cand_id;
+    int forced_n = 0;
+    const int32_t* forced_tok = nullptr;
+    const int32_t* forced_src = nullptr;
+    const float* forced_slp = nullptr;
+    void record_candidates(int R, bool step0);
+    void apply_forced(int step, const std::vector<std::vector<int64_t>>& old_rows);
 
     // graph replay of the decode step
     bool use_graph = true;
@@ -91,7 +102,7 @@ struct DecodeTask {
     void detect_language(int n_audio, int first_id, int n_lang, int32_t* out_ids, float* out_probs);
     void set_languages(const int32_t* lang, int n);
     void run_forced(int n_audio, int n_steps, const int32_t* ftok, const int32_t* fsrc, float* out_lp, int32_t* out_id,
-                    double* out_no_speech);
+                    double* out_no_speech, bool have_features = false);
 
     void upload_step(int rows_n);
     void step_decode(int rows_n);  // decoder_step + filter_topk for rows_n = n_audio*group rows (graph-replayed)

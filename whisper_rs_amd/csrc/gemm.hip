@@ -16,6 +16,7 @@
 // (cols = m); D[n][m]: lane l holds m = l&15 and n = 4*(l>>4)+r, r=0..3 -> 4 consecutive output
 // columns per lane = one vector store.
 #include "kernels.h"
+#include <atomic>
 
 namespace wrs {
 
@@ -24,13 +25,15 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // hipFuncSetAttribute is per device: a process that drives several GPUs (window pool) must raise the dynamic-LDS limit of a
-// kernel on each of them, once.  `done` is the kernel's own table of 64 flags.
-static void allow_dynamic_lds(const void* kernel, size_t bytes, bool (&done)[64]) {
+// kernel on each of them, once.  `done` is the kernel's own table of 64 flags
+// (atomic: worker threads of a window pool reach here concurrently).
+static void allow_dynamic_lds(const void* kernel, size_t bytes, std::atomic<bool> (&done)[64]) {
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || done[dev]) return;
+    if (dev < 0 || dev >= 64 || done[dev].load(std::memory_order_acquire)) return;
+    // concurrent first calls from several worker threads (window pool) may both set the attribute: idempotent
     HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    done[dev] = true;
+    done[dev].store(true, std::memory_order_release);
 }
 
 // ------------------------------------------------------------------------------------------ packing
@@ -620,6 +623,12 @@ __global__ __launch_bounds__(512) void gemm_f16_pp2_kernel(const GemmParams p) {
 
 static int gemm_pp2_min_wgs = 256;
 
+// test hook (wrs_debug_gemm_f16): force one kernel variant / report the variant the last launch took
+static int g_gemm_force = GEMM_AUTO;
+static int g_gemm_last = GEMM_AUTO;
+void gemm_debug_force(int kernel) { g_gemm_force = kernel; }
+int gemm_debug_last() { return g_gemm_last; }
+
 void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t N, int64_t K, const GemmEpi& e,
                      hipStream_t s) {
     WRS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_f16: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
@@ -639,37 +648,43 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     if (p.ksplit > 1)
         WRS_REQUIRE((K / 64) % p.ksplit == 0 && e.c_f32 && !e.bias && !e.residual && !e.posemb && !e.act && e.ldc % 4 == 0 && N % 4 == 0 &&
                         e.slab_stride >= M * e.ldc, "gemm_f16: bad split-K configuration");
+    if (A.packed) WRS_REQUIRE(A.packed_rows >= round_up(M, 128), "gemm_f16: packed A must hold a multiple of 128 rows (%ld < %ld)", (long)A.packed_rows, (long)round_up(M, 128));
+    const int force = g_gemm_force;
     // 256x256 ping-pong kernel: row-major activations, N a multiple of 256, grid fills the chip
     static const int pp2_mode = getenv("WRS_GEMM_PP2") ? atoi(getenv("WRS_GEMM_PP2")) : 1;  // 0 off, 1 auto, 2 always
     const int64_t pp2_tiles = cdiv(M, 256) * (N / 256);
-    if (!A.packed && N % 256 == 0 && (K / 32) % p.ksplit == 0 && (pp2_mode == 2 || (pp2_mode == 1 && pp2_tiles * p.ksplit >= gemm_pp2_min_wgs))) {
+    const bool pp2_ok = !A.packed && N % 256 == 0 && (K / 32) % p.ksplit == 0;
+    if (force == GEMM_PP2) WRS_REQUIRE(pp2_ok, "gemm_f16: the 256x256 kernel needs row-major A and N %% 256 == 0");
+    if (pp2_ok && (force == GEMM_PP2 || (force == GEMM_AUTO && (pp2_mode == 2 || (pp2_mode == 1 && pp2_tiles * p.ksplit >= gemm_pp2_min_wgs))))) {
         const dim3 g((unsigned)(8 * cdiv(pp2_tiles, 8)), (unsigned)p.ksplit);
         const size_t shmem = 4 * 2048 * 16;
-        static bool attr[64] = {};
+        static std::atomic<bool> attr[64];
         allow_dynamic_lds(reinterpret_cast<const void*>(gemm_f16_pp2_kernel), shmem, attr);
         gemm_f16_pp2_kernel<<<g, 512, shmem, s>>>(p);
+        g_gemm_last = GEMM_PP2;
         return;
     }
     const dim3 grid((unsigned)(8 * cdiv(tiles, 8)), (unsigned)p.ksplit);
     // decode-step shapes (packed activations) whose grid gives a CU at most one workgroup: loader/consumer ring kernels
     static const int ring_mode = getenv("WRS_GEMM_RING") ? atoi(getenv("WRS_GEMM_RING")) : 1;  // 0 off, 1 auto, 2 always
-    if (A.packed && A.packed_rows >= round_up(M, 128) && ring_mode != 0) {
-        if (tiles * p.ksplit <= 256 || (ring_mode == 2 && p.ksplit > 1)) {
-            const size_t shmem = 3 * 2048 * 16;
-            static bool attr[64] = {};
-            allow_dynamic_lds(reinterpret_cast<const void*>(gemm_f16_ring_kernel<4, 8>), shmem, attr);
-            gemm_f16_ring_kernel<4, 8><<<grid, 768, shmem, s>>>(p);
-            return;
-        }
+    if (force == GEMM_RING) WRS_REQUIRE(A.packed, "gemm_f16: the ring kernel needs packed activations");
+    if (A.packed && (force == GEMM_RING || (force == GEMM_AUTO && ring_mode != 0 && (tiles * p.ksplit <= 256 || (ring_mode == 2 && p.ksplit > 1))))) {
+        const size_t shmem = 3 * 2048 * 16;
+        static std::atomic<bool> attr[64];
+        allow_dynamic_lds(reinterpret_cast<const void*>(gemm_f16_ring_kernel<4, 8>), shmem, attr);
+        gemm_f16_ring_kernel<4, 8><<<grid, 768, shmem, s>>>(p);
+        g_gemm_last = GEMM_RING;
+        return;
         // (a 128x256 instantiation, 8 consumer + 4 loader waves, only equals the 4-wave kernel on the N = 3D / 4D shapes —
         // 24 vs 24 us, 29 vs 30 us: both are dominated by the fp32 / GELU epilogue — and is not used:
         // profiles/r01_gemm_ring_decode.log)
     }
     if (A.packed) {
-        WRS_REQUIRE(A.packed_rows >= round_up(M, 128), "gemm_f16: packed A must hold a multiple of 128 rows (%ld < %ld)", (long)A.packed_rows, (long)round_up(M, 128));
         gemm_f16_kernel<true><<<grid, 256, 0, s>>>(p);
+        g_gemm_last = GEMM_TILE128_PACKED;
     } else {
         gemm_f16_kernel<false><<<grid, 256, 0, s>>>(p);
+        g_gemm_last = GEMM_TILE128;
     }
 }
 
@@ -959,7 +974,7 @@ template <int MT, int KPS>
 static void launch_dec(const half_t* a, const half_t* wp, float* slab, int M, int N, int n_pad, int ksteps, int mtiles, int m_pad,
                        hipStream_t s) {
     const size_t shmem = (size_t)(MT + 4) * KPS * 1024;  // weight fragments of 4 waves + activation panel
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_dec_kernel<MT, KPS>), shmem, attr_set);
     dim3 grid((unsigned)(n_pad / 64), (unsigned)(ksteps / KPS), (unsigned)(mtiles / MT));
     gemm_dec_kernel<MT, KPS><<<grid, 256, shmem, s>>>(a, wp, slab, M, N, ksteps, m_pad);

@@ -81,6 +81,10 @@ struct GemmA {
     int64_t packed_rows = 0;               // rows the packed buffer holds (multiple of 16; must cover round_up(M, 128))
 };
 // C[M, N] = A[M, K] * W[N, K]^T ; K multiple of 64; W packed with n_pad multiple of 128
+// kernel variants of launch_gemm_f16 (test hook: gemm_debug_force picks one, gemm_debug_last reports the one taken)
+enum GemmKernel { GEMM_AUTO = 0, GEMM_PP2 = 1, GEMM_TILE128 = 2, GEMM_TILE128_PACKED = 3, GEMM_RING = 4 };
+void gemm_debug_force(int kernel);  // GEMM_AUTO restores the launcher's own choice; GEMM_TILE128 also stands for the packed-A form
+int gemm_debug_last();
 void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t N, int64_t K, const GemmEpi& epi,
                      hipStream_t s);
 

@@ -37,8 +37,10 @@ struct OutBuilder {
     std::vector<wrs_segment> segments;
     std::vector<int64_t> wseek;
     std::vector<double> wavg, wns;
+    bool truncated = false;
     void emit(wrs_transcribe_output* out) {
         memset(out, 0, sizeof(*out));
+        out->truncated = truncated ? 1 : 0;
         out->n_tokens = (int64_t)tokens.size();
         out->tokens = (int64_t*)malloc(sizeof(int64_t) * std::max<size_t>(1, tokens.size()));
         memcpy(out->tokens, tokens.data(), tokens.size() * sizeof(int64_t));
@@ -114,7 +116,7 @@ void simulate_transcribe(int ts_begin, int64_t n_audio_ctxs, int64_t n_frames, c
         ob.wns.push_back(0.0);
         const int64_t adv = absorb_window(ob, window_tokens + off, window_lens[w], seek, ts_begin, input_stride, time_precision, false);
         off += window_lens[w];
-        if (adv == 0) break;
+        if (adv == 0) { ob.truncated = true; break; }
         seek += adv;
     }
     ob.emit(out);
@@ -134,6 +136,20 @@ int64_t TranscribeTask::prepare_mel(const float* audio, int64_t n) {
 void TranscribeTask::run(const float* audio, int64_t n, wrs_transcribe_output* out) {
     WRS_REQUIRE(out, "transcribe: null output");
     const int64_t F = prepare_mel(audio, n);
+    run_from_mel(F, out);
+}
+
+// the loop of TranscribeTask::run_inner after its log-mel (transcribe.rs:113-243) on a caller-supplied spectrogram
+void TranscribeTask::run_mel(const float* mel, int64_t n_frames, wrs_transcribe_output* out) {
+    WRS_REQUIRE(out && mel && n_frames >= 1, "transcribe: bad mel argument");
+    m->use();
+    mel_dev.ensure((size_t)80 * n_frames * 4);
+    HIP_CHECK(hipMemcpyAsync(mel_dev.p, mel, (size_t)80 * n_frames * 4, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));  // the caller's buffer is free on return
+    run_from_mel(n_frames, out);
+}
+
+void TranscribeTask::run_from_mel(int64_t F, wrs_transcribe_output* out) {
     const int64_t input_stride = WRS_N_FRAMES / m->T;                   // :120
     const double time_precision = (double)input_stride * kQuantum;      // :122
     OutBuilder ob;
@@ -153,7 +169,10 @@ void TranscribeTask::run(const float* audio, int64_t n, wrs_transcribe_output* o
         ob.wns.push_back(o.no_speech_prob);
         const int64_t adv = absorb_window(ob, o.tokens, o.n_tokens, seek, tsb, input_stride, time_precision, false);
         free_decode_result(&res);
-        if (adv == 0 || ob.wseek.size() >= 10000) break;  // the reference would loop forever on a <|0.00|> pair
+        if (adv == 0 || ob.wseek.size() >= 10000) {  // the reference would loop forever on a <|0.00|> pair
+            ob.truncated = true;                     // reported: the rest of the audio was NOT transcribed
+            break;
+        }
         seek += adv;
     }
     ob.emit(out);

@@ -18,6 +18,8 @@ struct TranscribeTask {
     void configure(Model* model, const wrs_token_ids& ids, const wrs_transcribe_options& o);
     int64_t prepare_mel(const float* audio, int64_t n);  // whole-file log-mel into mel_dev; returns frames
     void run(const float* audio, int64_t n, wrs_transcribe_output* out);
+    void run_mel(const float* mel, int64_t n_frames, wrs_transcribe_output* out);  // mel [80, n_frames] f32 host
+    void run_from_mel(int64_t n_frames, wrs_transcribe_output* out);               // spectrogram already in mel_dev
     void run_chunked(const float* audio, int64_t n, int batch, wrs_transcribe_output* out);
 };
 
