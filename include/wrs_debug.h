@@ -120,6 +120,11 @@ int wrs_debug_sequencer_run(const wrs_token_ids* ids, const wrs_decode_options* 
 int wrs_debug_transcribe_bookkeeping(int32_t ts_begin, int64_t n_audio_ctxs, int64_t n_frames, const int64_t* prompt, int64_t n_prompt,
                                      const int64_t* window_tokens, const int32_t* window_lens, int32_t n_windows, const wrs_tokenizer* tok,
                                      wrs_transcribe_output* out);
+/* f32 PARITY MODE (csrc/parity_f32.hip): every weight, activation, K/V cache entry and product of the model in fp32
+ * (v_mfma_f32_16x16x4_f32 GEMMs, fp32 attention).  Exists to demonstrate "token ids bit-exact": in this mode the
+ * free-running decode must reproduce the fp32 oracle's ids and beam sources to the last step.  Slow, small models only;
+ * choose before wrs_model_finalize (also: environment WRS_PARITY_F32=1 at wrs_model_create). */
+int wrs_debug_model_set_parity_f32(wrs_model* m, int enabled);
 int wrs_debug_set_encoder_stop(wrs_model* m, int n_launches);
 int wrs_debug_read_encoder(wrs_model* m, int which, float* out, int64_t n);
 

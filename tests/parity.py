@@ -5,7 +5,7 @@ free-running comparison must either match the oracle to the last step or every d
 that fp16 rounding explains:
 
   * every candidate (token, log-prob) the device proposes at a step where its state equals the oracle's is compared with
-    the oracle's own log-prob of that token: |error| <= CAND_ERR (measured worst 4e-3; asserted 6e-3);
+    the oracle's own log-prob of that token: |error| <= CAND_ERR (measured worst 2.6e-3; asserted 5e-3);
   * at a split (device and oracle select different beams at step s) the ORACLE's scores of the two selections are
     compared rank by rank: margin = max_j |score_o(oracle pick j) - score_o(device pick j)|.  The split is explained only
     if margin <= 2 * CAND_ERR + 2 * drift, where drift is the measured difference of the cumulative scores going into
@@ -25,7 +25,7 @@ import torch
 from whisper_rs_amd import debug as DBG
 from oracle import decode as OD
 
-CAND_ERR = 6e-3      # per-candidate log-prob error bound (fp16 path vs fp32 oracle), asserted everywhere; measured <= 4e-3
+CAND_ERR = 5e-3      # per-candidate log-prob error bound (fp16 path vs fp32 oracle), asserted everywhere; measured <= 3e-3
 DRIFT_TOL = 2e-2     # cumulative-score difference allowed between re-synchronisations
 MAX_RESYNC = 12
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -141,7 +141,7 @@ def compare_outputs(gouts, oouts, lp_tol=DRIFT_TOL):
         assert abs(g.no_speech_prob - o.no_speech_prob) < 1e-4 + 0.02 * o.no_speech_prob
 
 
-def run_with_resync(case, task, mel, view, G, eot, exact=False):
+def run_with_resync(case, task, mel, view, G, eot, exact=False, cand_tol=CAND_ERR):
     """Free-running device decode of `mel` compared with the oracle run `view` (OracleView).  Returns the list of
     explained near-tie splits (empty = bit-exact ids and sources to the last step).  exact=True forbids splits."""
     ot, os_, ol = view.tok, view.src, view.slp
@@ -156,7 +156,7 @@ def run_with_resync(case, task, mel, view, G, eot, exact=False):
         split = None
         for s in range(forced, n):
             olp_full = view.olp(s)
-            worst = max(worst, check_candidates(glp[s], gid[s], olp_full, s))
+            worst = max(worst, check_candidates(glp[s], gid[s], olp_full, s, cand_tol))
             if not (np.array_equal(gt[s], ot[s]) and np.array_equal(gs[s], os_[s])):
                 split = s
                 break
@@ -186,23 +186,23 @@ def teacher_forced_check(case, glp, gid, gns, view, G, eot, min_exact_frac):
     steps, R = ot.shape
     rows = [list(r) for r in view.initial_rows]
     slp = torch.zeros(R)
-    exact, worst, splits = 0, 0.0, []
+    worst, splits = 0.0, []
     for s in range(steps):
         olp_full = view.olp(s)
         worst = max(worst, check_candidates(glp[s], gid[s], olp_full, s))
         work = slp.clone()
         nt, src, _ = OD.beam_select(rows, work, torch.from_numpy(glp[s]), torch.from_numpy(gid[s].astype(np.int64)), G, eot)
         sel_tok, sel_src = np.array([t[-1] for t in nt]), np.array(src)
-        if np.array_equal(sel_tok, ot[s]) and np.array_equal(sel_src, os_[s]):
-            exact += 1
-        else:
+        if not (np.array_equal(sel_tok, ot[s]) and np.array_equal(sel_src, os_[s])):
             splits += explain_split(case, s, G, slp.numpy(), slp.numpy(), olp_full, ot[s], os_[s], sel_tok, sel_src, eot)
         rows = [rows[os_[s][r]] + [int(ot[s][r])] for r in range(R)]
         slp = torch.from_numpy(ol[s].copy())
     if gns is not None:
         for a in range(len(oouts)):
             assert abs(gns[a] - oouts[a].no_speech_prob) < 1e-4 + 0.02 * oouts[a].no_speech_prob
-    print(f"[parity] {case}: {steps} steps teacher-forced over {R} rows, {exact} exact selections, {len(splits)} explained near-ties "
-          f"{[(r['step'], r['audio'], round(r['margin'], 5)) for r in splits]}, worst candidate error {worst:.2e}")
-    assert exact >= min_exact_frac * steps, f"{case}: only {exact}/{steps} steps reproduced the oracle's selection exactly"
-    return exact, steps, splits
+    total = steps * (R // G)  # (step, audio) selections; every one that is not exact was shown above to be a near-tie
+    exact = total - len(splits)
+    print(f"[parity] {case}: {steps} steps teacher-forced over {R} rows: {exact}/{total} (step, audio) selections exact, {len(splits)} explained "
+          f"near-ties {[(r['step'], r['audio'], round(r['margin'], 5)) for r in splits]}, worst candidate error {worst:.2e}")
+    assert exact >= min_exact_frac * total, f"{case}: only {exact}/{total} selections reproduced the oracle's exactly"
+    return exact, total, splits

@@ -38,13 +38,13 @@ def test_wide_decode_480_rows_teacher_forced(gpu):
     the benchmark runs (model.cpp dec_big_gemm_rows).  Decoder-only (features in), every step against the oracle."""
     n = 96
     assert n * 5 >= 480
-    exact, steps = _teacher_forced_check(gpu, "wide", n, 10, 0.9, feats=_features(n, 7), ids=TokenIds.multilingual())
+    exact, steps = _teacher_forced_check(gpu, "wide", n, 10, 0.95, feats=_features(n, 7), ids=TokenIds.multilingual())
     print(f"wide, {n * 5} rows: {exact}/{steps} selections reproduced exactly")
 
 
 def test_wide_decode_small_batch_teacher_forced(gpu):
     """3 audios x beam 5 = 15 rows at the same width: the latency-optimised split-K path (gemm_dec / skinny logits)."""
-    exact, steps = _teacher_forced_check(gpu, "wide", 3, 24, 0.9, feats=_features(3, 8), ids=TokenIds.multilingual())
+    exact, steps = _teacher_forced_check(gpu, "wide", 3, 24, 0.95, feats=_features(3, 8), ids=TokenIds.multilingual())
     print(f"wide, 15 rows: {exact}/{steps} selections reproduced exactly")
 
 

@@ -212,6 +212,14 @@ int wrs_debug_transcribe_bookkeeping(int32_t ts_begin, int64_t n_audio_ctxs, int
         simulate_transcribe(ts_begin, n_audio_ctxs, n_frames, prompt, n_prompt, window_tokens, window_lens, n_windows, tok ? &tok->t : nullptr, out);
     });
 }
+// f32 parity mode (csrc/parity_f32.hip): must be chosen before wrs_model_finalize
+int wrs_debug_model_set_parity_f32(wrs_model* h, int enabled) {
+    return guarded([&] {
+        WRS_REQUIRE(h, "null model");
+        WRS_REQUIRE(!h->m.finalized, "wrs_debug_model_set_parity_f32: the model is already finalized");
+        h->m.parity_f32 = enabled != 0;
+    });
+}
 int wrs_debug_set_encoder_stop(wrs_model* h, int n_launches) { if (h) h->m.debug_enc_stop = n_launches; return 0; }
 // copy an internal encoder workspace buffer to host as f32. which: 0 x(f32) 1 xn 2 qkv 3 att 4 h 5 c1 6 mel_t 7 xa16
 int wrs_debug_read_encoder(wrs_model* h, int which, float* out, int64_t n) {

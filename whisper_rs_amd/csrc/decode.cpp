@@ -41,6 +41,7 @@ bool DecodeTask::side_idle() {
 void DecodeTask::encode_async(const float* audio, int n_audio, int mem_kind) {
     WRS_REQUIRE(audio && n_audio >= 1 && n_audio <= max_audio, "encode_async: %d windows exceed the task capacity %d", n_audio, max_audio);
     WRS_REQUIRE(pending.size() < 2, "encode_async: two batches are already queued (call run_pending first)");
+    WRS_REQUIRE(!m->parity_f32, "encode_async: the f32 parity mode has no overlapped path");
     m->use();
     if (!side) {
         int prio_least = 0, prio_greatest = 0;

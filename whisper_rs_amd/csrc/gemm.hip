@@ -1019,7 +1019,8 @@ __device__ __forceinline__ int float_order_key(float f) {
 template <int MODE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, int64_t lda, int64_t rpb, int64_t bs,
                                                        const float* __restrict__ w, int64_t ldw, int M, int N, int K,
-                                                       float* __restrict__ c, int64_t ldc, int* __restrict__ maxbuf) {
+                                                       float* __restrict__ c, int64_t ldc, int* __restrict__ maxbuf,
+                                                       const GemmF32Epi e = GemmF32Epi()) {
     __shared__ float As[64][17];
     __shared__ float Ws[64][17];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1070,7 +1071,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int n = n0 + wy * 32 + i * 16 + 4 * (lane >> 4);
-            if (MODE == 0) {
+            if (MODE == 2) {  // f32 parity mode: bias, scale, exact GELU, positional embedding, residual; remapped C rows
+                if (valid) {
+                    const int64_t mb = mm / e.c_rpb, mr = mm % e.c_rpb;
+                    const int64_t crow = mb * e.c_brows + mr + e.c_roff;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int nn = n + r;
+                        if (nn < N) {
+                            float x = acc[i][j][r];
+                            if (e.bias) x += e.bias[nn];
+                            if (nn < e.scale_n_end) x *= e.scale;
+                            if (e.act) x = 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+                            if (e.posemb) x += e.posemb[mr * N + nn];
+                            if (e.residual) x += e.residual[crow * e.ldc + nn];
+                            e.c[crow * e.ldc + nn] = x;
+                        }
+                    }
+                }
+            } else if (MODE == 0) {
                 const int b0 = n >> 1;
                 if (valid && b0 < ldc) c[mm * ldc + b0] = acc[i][j][0] * acc[i][j][0] + acc[i][j][1] * acc[i][j][1];
                 if (valid && b0 + 1 < ldc) c[mm * ldc + b0 + 1] = acc[i][j][2] * acc[i][j][2] + acc[i][j][3] * acc[i][j][3];
@@ -1113,6 +1132,14 @@ void launch_gemm_f32(const float* a, int64_t lda, int64_t rows_per_batch, int64_
     else
         gemm_f32_kernel<1><<<grid, 256, 0, s>>>(a, lda, rows_per_batch, batch_stride, w, ldw, (int)M, (int)N, (int)K, c, ldc,
                                                 reinterpret_cast<int*>(maxbuf));
+}
+
+void launch_gemm_f32_epi(const float* a, int64_t lda, int64_t rows_per_batch, int64_t batch_stride, const float* w, int64_t ldw,
+                         int64_t M, int64_t N, int64_t K, const GemmF32Epi& e, hipStream_t s) {
+    WRS_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldw % 4 == 0 && batch_stride % 4 == 0, "gemm_f32: alignment");
+    WRS_REQUIRE(M > 0 && M < (1ll << 31) && N > 0 && e.c && e.ldc >= N, "gemm_f32: bad shape");
+    dim3 grid((unsigned)cdiv(M, 64), (unsigned)cdiv(N, 64));
+    gemm_f32_kernel<2><<<grid, 256, 0, s>>>(a, lda, rows_per_batch, batch_stride, w, ldw, (int)M, (int)N, (int)K, e.c, e.ldc, nullptr, e);
 }
 
 }  // namespace wrs

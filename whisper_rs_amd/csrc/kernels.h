@@ -123,6 +123,22 @@ void launch_gemm_f32(const float* a, int64_t lda, int64_t rows_per_batch, int64_
                      int64_t ldw, int64_t M, int64_t N, int64_t K, int mode, float* c, int64_t ldc, float* maxbuf,
                      hipStream_t s);
 
+// mode 2 (f32 parity mode, parity_f32.hip): C[crow(m)][n] = act((acc + bias[n]) * (n < scale_n_end ? scale : 1)) + posemb + residual
+struct GemmF32Epi {
+    const float* bias = nullptr;
+    float scale = 1.f;
+    int scale_n_end = 0;
+    int act = 0;                       // 1 = exact GELU (erff)
+    const float* residual = nullptr;   // addressed like C; may alias C
+    const float* posemb = nullptr;     // [c_rpb, N]
+    float* c = nullptr;
+    int64_t ldc = 0;
+    int64_t c_rpb = 1ll << 40, c_brows = 0, c_roff = 0;  // C row of m = (m / c_rpb) * c_brows + m % c_rpb + c_roff
+};
+// W row-major [round_up(N, 64), ldw] (rows >= N zero); K % 16 == 0
+void launch_gemm_f32_epi(const float* a, int64_t lda, int64_t rows_per_batch, int64_t batch_stride, const float* w, int64_t ldw,
+                         int64_t M, int64_t N, int64_t K, const GemmF32Epi& epi, hipStream_t s);
+
 // ---------------------------------------------------------------- mel
 void launch_reflect_pad(const float* audio, int64_t n_batch, int64_t n, float* out, int64_t out_stride, hipStream_t s);
 void launch_fill_f32(float* p, float v, int64_t n, hipStream_t s);

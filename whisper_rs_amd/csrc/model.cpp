@@ -259,7 +259,10 @@ void Model::finalize() {
         owned.push_back(std::move(b));
     }
     enc.resize(L_enc);
-    for (int i = 0; i < L_enc; ++i) build_block(*this, enc[i], "encoder.blocks." + std::to_string(i), D, false);
+    for (int i = 0; i < L_enc; ++i) {
+        if (parity_f32) build_block_f32(*this, enc[i], "encoder.blocks." + std::to_string(i), D, false, staging);
+        build_block(*this, enc[i], "encoder.blocks." + std::to_string(i), D, false);
+    }
     ln_post_g = keep_f32(*this, need(*this, "encoder.ln_post.weight"), D);
     ln_post_b = keep_f32(*this, need(*this, "encoder.ln_post.bias"), D);
 
@@ -274,9 +277,13 @@ void Model::finalize() {
         dec_pos = keep_f32(*this, need(*this, "decoder.positional_embedding"), (int64_t)n_ctx * D);
     }
     dec.resize(L_dec);
-    for (int i = 0; i < L_dec; ++i) build_block(*this, dec[i], "decoder.blocks." + std::to_string(i), D, true);
+    for (int i = 0; i < L_dec; ++i) {
+        if (parity_f32) build_block_f32(*this, dec[i], "decoder.blocks." + std::to_string(i), D, true, staging);
+        build_block(*this, dec[i], "decoder.blocks." + std::to_string(i), D, true);
+    }
     ln_g = keep_f32(*this, need(*this, "decoder.ln.weight"), D);
     ln_b = keep_f32(*this, need(*this, "decoder.ln.bias"), D);
+    if (parity_f32) finalize_f32();
     HIP_CHECK(hipStreamSynchronize(stream));
     staging.clear();
     finalized = true;
@@ -312,11 +319,19 @@ void Model::load_mel(const float* mel, int n, int mem_kind, int64_t n_frames, in
         src = tmp.as<float>();
     }
     launch_mel_prep(src, n, n_frames, 80 * n_frames, seek, enc_ws.mel_t.as<half_t>(), stream);
+    if (parity_f32) load_mel_f32(src, n, n_frames, 80 * n_frames, seek);
     if (mem_kind == WRS_MEM_HOST) HIP_CHECK(hipStreamSynchronize(stream));  // tmp is freed on return
+}
+
+void Model::load_mel_window(const float* mel_dev, int64_t n_frames, int64_t seek, int slot) {
+    WRS_REQUIRE(slot >= 0 && slot < enc_ws.cap, "load_mel_window: slot %d out of range", slot);
+    launch_mel_prep(mel_dev, 1, n_frames, 80 * n_frames, seek, enc_ws.mel_t.as<half_t>() + (size_t)slot * 3002 * 80, stream);
+    if (parity_f32) load_mel_f32(mel_dev, 1, n_frames, 80 * n_frames, seek, slot);
 }
 
 void Model::encoder_from_mel_t(int n) {
     WRS_REQUIRE(finalized, "model not finalized");
+    if (parity_f32) { encoder_f32(n); return; }
     WRS_REQUIRE(n >= 1 && n <= enc_ws.cap, "encoder: bad window count %d", n);
     EncoderWorkspace& w = enc_ws;
     w.n_encoded = n;
@@ -436,10 +451,12 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.n_audio = 0;
     st.pending_src.clear();
     if (const char* e = getenv("WRS_DEC_BIG_GEMM_ROWS")) dec_big_gemm_rows = atoi(e);
+    if (parity_f32) init_state_f32(st);
 }
 
 void Model::load_cross_kv(DecState& st, const half_t* xa16, int n_audio) {
     WRS_REQUIRE(n_audio >= 1 && n_audio <= st.a_cap, "cross K/V: %d audios exceed capacity %d", n_audio, st.a_cap);
+    if (parity_f32) { load_cross_kv_f32(st, n_audio); return; }  // from enc_ws.xa32, which always accompanies xa16
     const int64_t M = (int64_t)n_audio * T;
     const float scale = std::pow((float)(D / H), -0.25f);
     const size_t per_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
@@ -477,6 +494,7 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     WRS_REQUIRE(rows >= 1 && rows <= st.r_cap, "decoder_step: bad row count %d", rows);
     WRS_REQUIRE((rows - 1) * phys_mul < st.r_cap, "decoder_step: physical row out of range");
     WRS_REQUIRE(rows % q_per_audio == 0 && rows / q_per_audio <= st.n_audio, "decoder_step: rows %d do not match %d audios x %d", rows, st.n_audio, q_per_audio);
+    if (parity_f32) { decoder_step_f32(st, rows, phys_mul, q_per_audio, update_anc, want_logits); return; }
     const float scale = std::pow((float)(D / H), -0.25f);
     const StepParams* sp = st.sp_d();
     const int64_t anc_stride = (int64_t)st.r_cap * n_ctx;

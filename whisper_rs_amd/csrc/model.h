@@ -25,6 +25,20 @@ struct BlockW {
     float* mlp0_b = nullptr;
     half_t* mlp2_w = nullptr;
     float* mlp2_b = nullptr;
+    // f32 parity mode only (parity_f32.hip): row-major fp32 copies of the matrices
+    float *qkv_w32 = nullptr, *out_w32 = nullptr, *cq_w32 = nullptr, *ckv_w32 = nullptr, *cout_w32 = nullptr, *mlp0_w32 = nullptr,
+          *mlp2_w32 = nullptr;
+};
+
+// f32 parity mode workspaces
+struct EncoderWorkspaceF32 {
+    int cap = 0;
+    DevBuf mel_t, c1, xn, qkv, att, h;
+};
+struct DecStateF32 {
+    DevBuf cross;    // [L][a_cap][T][2D]: K (scaled) | V
+    DevBuf kc, vc;   // [L][r_cap][n_ctx][D]
+    DevBuf xn, qkv, att, h;
 };
 
 struct EncoderWorkspace {
@@ -48,6 +62,7 @@ struct DecState {
     DevBuf kc, vc;              // [L][r_cap][n_ctx][D]
     DevBuf anc;                 // [2][r_cap][n_ctx]
     DevBuf x, xn, att, h, slab, logits, ckv_tmp;
+    std::unique_ptr<DecStateF32> f32;  // f32 parity mode only
     DevBuf sp_dev;              // StepParams + tokens[r_cap] + src[r_cap] + ts_mode[r_cap]
     PinnedBuf sp_host;
     PinnedBuf topk;             // lp [r_cap*8] f32 | id [r_cap*8] i32 | no_speech [r_cap] f32
@@ -99,6 +114,19 @@ struct Model {
     std::vector<BlockW> dec;
     float *ln_g = nullptr, *ln_b = nullptr;
 
+    // f32 parity mode (parity_f32.hip; wrs_debug_model_set_parity_f32 / WRS_PARITY_F32=1 before finalize): fp32 weights,
+    // activations, caches and products, to demonstrate bit-exact token ids against the fp32 oracle.  Test aid, slow.
+    bool parity_f32 = false;
+    float *conv1_w32 = nullptr, *conv2_w32 = nullptr, *emb32 = nullptr;
+    EncoderWorkspaceF32 enc_ws32;
+    void finalize_f32();
+    void ensure_encoder_ws_f32(int n);
+    void load_mel_f32(const float* mel_dev, int n, int64_t n_frames, int64_t mel_bs, int64_t seek, int slot = 0);
+    void encoder_f32(int n);
+    void init_state_f32(DecState& st);
+    void load_cross_kv_f32(DecState& st, int n_audio);
+    void decoder_step_f32(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits);
+
     EncoderWorkspace enc_ws;
     std::unique_ptr<DecState> stage_state;  // used by the stage API (wrs_decoder_forward)
     StageTimer* timer = nullptr;            // optional per-kernel timing sink
@@ -128,6 +156,8 @@ struct Model {
     void encoder_from_mel_t(int n);
     // upload mel [n,80,3000] f32 (host or device) into enc_ws.mel_t
     void load_mel(const float* mel, int n, int mem_kind, int64_t n_frames, int64_t seek);
+    // window `slot` of the encoder input = frames seek..seek+3000 of a device-resident spectrogram [80, n_frames]
+    void load_mel_window(const float* mel_dev, int64_t n_frames, int64_t seek, int slot);
 
     // decoder
     void init_state(DecState& st, int a_cap, int group);
@@ -184,6 +214,7 @@ struct Timed {
 };
 
 // shape the architecture expects for a VarStore path; false for names the model does not have
+void build_block_f32(Model& m, BlockW& bw, const std::string& pre, int64_t d, bool cross, const std::map<std::string, DevBuf>& staging);
 bool expected_shape(const Model& m, const std::string& name, std::vector<int64_t>& shape);
 // weights_io.cpp: reads every tensor of the architecture found in a safetensors file; returns how many were set
 int load_safetensors(Model& m, const char* path);

@@ -159,7 +159,7 @@ void TranscribeTask::run_from_mel(int64_t F, wrs_transcribe_output* out) {
     const int tsb = dt.ids.ts_begin;
     m->ensure_encoder_ws(1);
     while (seek < F) {  // :151
-        launch_mel_prep(mel_dev.as<float>(), 1, F, 80 * F, seek, m->enc_ws.mel_t.as<half_t>(), m->stream);  // :152
+        m->load_mel_window(mel_dev.as<float>(), F, seek, 0);  // :152 (pad_or_trim of mel[:, seek:])
         if (condition) dt.set_prompt(ob.tokens.data(), (int)ob.tokens.size());  // :155-158
         wrs_decode_result res;
         dt.run_loaded(1, &res);  // :161-162
@@ -194,8 +194,7 @@ void TranscribeTask::run_chunked(const float* audio, int64_t n, int batch, wrs_t
     for (int64_t w0 = 0; w0 < n_win; w0 += batch) {
         const int nb = (int)std::min<int64_t>(batch, n_win - w0);
         for (int j = 0; j < nb; ++j)
-            launch_mel_prep(mel_dev.as<float>(), 1, F, 80 * F, (w0 + j) * WRS_N_FRAMES,
-                            m->enc_ws.mel_t.as<half_t>() + (size_t)j * 3002 * 80, m->stream);
+            m->load_mel_window(mel_dev.as<float>(), F, (w0 + j) * WRS_N_FRAMES, j);
         wrs_decode_result res;
         dt.run_loaded(nb, &res);
         for (int j = 0; j < nb; ++j) {

@@ -53,6 +53,7 @@ SYMBOLS = {
                                          P(L.DecodeResultC), C.c_void_p, C.c_void_p, C.c_void_p]),
     "wrs_debug_transcribe_bookkeeping": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                                    C.c_void_p, P(L.TranscribeOutputC)]),
+    "wrs_debug_model_set_parity_f32": (C.c_int, [C.c_void_p, C.c_int]),
     "wrs_debug_set_encoder_stop": (C.c_int, [C.c_void_p, C.c_int]),
     "wrs_debug_read_encoder": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
 }
@@ -149,3 +150,12 @@ def decode_forced_features(task, feats, forced_tokens, forced_sources):
     ns = np.empty(feats.shape[0], np.float64)
     L.check(l.wrs_debug_decode_forced_features(task._h, _p(feats), feats.shape[0], steps, _p(ft), _p(fs), _p(lp), _p(ids), _p(ns)))
     return lp, ids, ns
+
+
+def parity_f32_model(dims, weights, device=0):
+    """a model in f32 parity mode (include/wrs_debug.h): fp32 everywhere, for the bit-exact-ids demonstration."""
+    from .api import Whisper
+    m = Whisper(dims, device=device)
+    L.check(lib().wrs_debug_model_set_parity_f32(m._h, 1))
+    m.load(weights)
+    return m
