@@ -96,6 +96,7 @@ struct AttnParams {
     const float* q_bias;
     float q_scale;
     int n_units;  // !SPLIT: n_batch * H
+    int causal;   // !SPLIT: query i of a batch item attends to keys 0..i only (decoder prompt prefill, reference model.rs:191-201 mask)
 };
 
 #ifndef XA_WAVES
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
     const int64_t head_base = ((int64_t)b * p.H + h) * (int64_t)p.Tp * 64;
     const half_t* kbase = p.kp + head_base + lane * 8;
     const half_t* vbase = p.vp + head_base + lane * 8;
-    const int n_blocks = p.Tp / 32;
+    int n_blocks = p.Tp / 32;
+    if (!SPLIT && p.causal) n_blocks = min(n_blocks, (q0 + 16 * NQ - 1) / 32 + 1);  // key blocks past the wave's last query are fully masked
     const int kb_begin = SPLIT ? wave : 0, kb_step = SPLIT ? XA_WAVES : 1;
 
     floatx4 o[NQ][4];
@@ -235,6 +237,14 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
                 for (int j = 0; j < 8; ++j) {
                     const int key = kb * 32 + (j < 4 ? 4 * qg + j : 16 + 4 * qg + (j - 4));
                     if (key >= p.T) sv[j] = -INFINITY;
+                }
+            }
+            if (!SPLIT && p.causal && kb * 32 + 31 > q0 + t * 16) {  // block reaches past the tile's first query: mask key > query
+                const int qi = q0 + t * 16 + qcol;                    // (block 0 always holds key 0 <= query: the running max stays finite)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = kb * 32 + (j < 4 ? 4 * qg + j : 16 + 4 * qg + (j - 4));
+                    if (key > qi) sv[j] = -INFINITY;
                 }
             }
             float bm = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
@@ -317,9 +327,10 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
 }
 
 void launch_attn_full(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_batch, int Tq, int T, int H,
-                      half_t* out, int64_t ldo, hipStream_t s) {
+                      half_t* out, int64_t ldo, hipStream_t s, bool causal) {
     WRS_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && T >= 1 && Tq >= 1, "attn_full: bad shape");
-    AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, Tq, 0, out, ldo, nullptr, 0, 0, nullptr, 1.f, n_batch * H};
+    WRS_REQUIRE(!causal || Tq == T, "attn_full: causal attention needs as many keys as queries");
+    AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, Tq, 0, out, ldo, nullptr, 0, 0, nullptr, 1.f, n_batch * H, causal ? 1 : 0};
     const int64_t units8 = cdiv((int64_t)n_batch * H, 8);
     static const int nq = getenv("WRS_ATTN_NQ") ? atoi(getenv("WRS_ATTN_NQ")) : ENC_ATTN_NQ;
     if (nq == 4) attn_mfma_kernel<false, 4><<<(unsigned)(8 * units8 * cdiv(Tq, 256)), 256, 0, s>>>(p);
@@ -331,7 +342,7 @@ void launch_attn_cross(const float* q_slab, int q_ksplit, int q_m_pad, const flo
                        const half_t* vp, int n_audio, int G, int T, int H, half_t* out, hipStream_t s) {
     WRS_REQUIRE(G >= 1 && G <= 16, "attn_cross: group size %d not in 1..16", G);
     WRS_REQUIRE(T >= 1 && q_slab && q_bias && q_ksplit >= 1, "attn_cross: bad argument");
-    AttnParams p{nullptr, 0, kp, vp, T, (int)round_up(T, 32), H, G, G, out, 0, q_slab, q_ksplit, q_m_pad, q_bias, q_scale, 0};
+    AttnParams p{nullptr, 0, kp, vp, T, (int)round_up(T, 32), H, G, G, out, 0, q_slab, q_ksplit, q_m_pad, q_bias, q_scale, 0, 0};
     dim3 grid(1, (unsigned)H, (unsigned)n_audio);
     attn_mfma_kernel<true, 1><<<grid, XA_WAVES * 64, 0, s>>>(p);
 }

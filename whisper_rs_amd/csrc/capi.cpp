@@ -116,6 +116,22 @@ int wrs_decoder_forward(wrs_model* h, const int64_t* tokens, int n_batch, int n_
         }
         WRS_REQUIRE(st.len + n_tokens <= m.n_ctx && offset + n_tokens <= m.n_ctx, "wrs_decoder_forward: %d cached + %d new tokens (offset %ld) exceed n_text_ctxs %d",
                     st.len, n_tokens, (long)offset, m.n_ctx);
+        if (n_tokens > 1 && st.len == 0 && !m.parity_f32) {
+            // all tokens in one masked pass, as the reference does (model.rs:191-201,490-522): batched causal prefill
+            std::vector<int> toks((size_t)n_batch * n_tokens);
+            for (size_t i = 0; i < toks.size(); ++i) {
+                WRS_REQUIRE(tokens[i] >= 0 && tokens[i] < m.V, "wrs_decoder_forward: token %ld out of range", (long)tokens[i]);
+                toks[i] = (int)tokens[i];
+            }
+            WRS_REQUIRE(offset == 0, "wrs_decoder_forward: a multi-token call on an empty cache starts at offset 0 (got %ld)", (long)offset);
+            st.pending_src.clear();
+            m.decoder_prefill(st, n_batch, n_tokens, 0, 1, toks.data(), true);
+            HIP_CHECK(hipMemcpy2DAsync(logits, (size_t)m.V * 4, st.prefill.logits_all.p, (size_t)st.logits_ld * 4, (size_t)m.V * 4,
+                                       (size_t)n_batch * n_tokens, hipMemcpyDeviceToHost, m.stream));
+            HIP_CHECK(hipStreamSynchronize(m.stream));
+            st.len = n_tokens;
+            return;
+        }
         for (int t = 0; t < n_tokens; ++t) {
             StepParams* sp = st.sp_h();
             st.parity ^= 1;

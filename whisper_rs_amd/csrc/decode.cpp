@@ -388,6 +388,61 @@ bool DecodeTask::update_greedy(int n_audio, bool step0, const float* lp, const i
     return completed;
 }
 
+// The decoder's first forward pass (decode/mod.rs:234-258): the S = sample_begin prompt tokens of every audio, on one row
+// per audio.  Leaves the step-0 candidates (top-k of the filtered logits of the last prompt position) in the pinned
+// buffer and the no-speech probabilities (softmax of the raw logits at sot_idx, :250-255) in no_speech_out[n_audio].
+// S >= 2: one batched causal pass (Model::decoder_prefill); S == 1, the f32 parity mode or WRS_PREFILL_SEQUENTIAL=1:
+// one decoder step per position.
+void DecodeTask::prefill(int n_audio, double* no_speech_out) {
+    const int G = group, S = sample_begin;
+    const int k = (mode == WRS_EXTRACT_BEAM_SEARCH) ? G + 1 : 1;
+    const FilterCfg cfg = filter_cfg();
+    hipStream_t s = m->stream;
+    static const bool sequential_env = getenv("WRS_PREFILL_SEQUENTIAL") && getenv("WRS_PREFILL_SEQUENTIAL")[0] == '1';
+    auto filter_at = [&](bool want_ns) {
+        StepParams* sp = st.sp_h();
+        sp->cache_pos = S - 1; sp->pos_idx = S - 1; sp->parity = 0; sp->first_step = 1;
+        sp->want_no_speech = want_ns ? 1 : 0; sp->n_rows = n_audio;
+        for (int a = 0; a < n_audio; ++a) st.tsmode_h()[a] = 0;
+        upload_step(n_audio);
+    };
+    if (S >= 2 && !m->parity_f32 && !sequential_env) {
+        std::vector<int> toks((size_t)n_audio * S);
+        for (int a = 0; a < n_audio; ++a)
+            for (int p = 0; p < S; ++p) toks[(size_t)a * S + p] = (int)initial_token(a, p);
+        m->decoder_prefill(st, n_audio, S, 0, G, toks.data(), false);
+        if (sot_idx != S - 1) {  // no-speech probability from the logits at the sot position
+            filter_at(true);
+            m->prefill_logits(st, n_audio, S, sot_idx);
+            launch_filter_topk(st.logits.as<float>(), n_audio, cfg, st.sp_d(), st.tsmode_d(), k, st.topk_lp_d(), st.topk_id_d(), st.no_speech_d(), nullptr, s);
+            HIP_CHECK(hipStreamSynchronize(s));  // also: `toks` and the pinned step block are free again
+            for (int a = 0; a < n_audio; ++a) no_speech_out[a] = (double)st.no_speech_h()[a];
+        }
+        filter_at(sot_idx == S - 1);
+        m->prefill_logits(st, n_audio, S, S - 1);
+        launch_filter_topk(st.logits.as<float>(), n_audio, cfg, st.sp_d(), st.tsmode_d(), k, st.topk_lp_d(), st.topk_id_d(), st.no_speech_d(), nullptr, s);
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (sot_idx == S - 1)
+            for (int a = 0; a < n_audio; ++a) no_speech_out[a] = (double)st.no_speech_h()[a];
+        return;
+    }
+    for (int p = 0; p < S; ++p) {
+        StepParams* sp = st.sp_h();
+        sp->cache_pos = p; sp->pos_idx = p; sp->parity = 0; sp->first_step = 1;
+        sp->want_no_speech = (p == sot_idx) ? 1 : 0; sp->n_rows = n_audio;
+        for (int a = 0; a < n_audio; ++a) { st.tokens_h()[a] = (int)initial_token(a, p); st.src_h()[a] = a; st.tsmode_h()[a] = 0; }
+        upload_step(n_audio);
+        const bool want_logits = (p == S - 1) || p == sot_idx;
+        m->decoder_step(st, n_audio, G, 1, false, want_logits);
+        if (want_logits)
+            launch_filter_topk(st.logits.as<float>(), n_audio, cfg, st.sp_d(), st.tsmode_d(), k, st.topk_lp_d(), st.topk_id_d(), st.no_speech_d(), nullptr, s);
+        // the pinned step-parameter block is rewritten for the next position: its async H2D copy must have run
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (p == sot_idx)
+            for (int a = 0; a < n_audio; ++a) no_speech_out[a] = (double)st.no_speech_h()[a];  // decode/mod.rs:250-255
+    }
+}
+
 void DecodeTask::run_loaded(int n_audio, wrs_decode_result* out) {
     WRS_REQUIRE(n_audio >= 1 && n_audio <= max_audio, "run: %d windows exceed the task capacity %d", n_audio, max_audio);
     m->use();
@@ -443,28 +498,9 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
     const int k = (mode == WRS_EXTRACT_BEAM_SEARCH) ? G + 1 : 1;
     const FilterCfg cfg = filter_cfg();
 
-    // ---- forward pass i = 0 (decode/mod.rs:234-245): the S prompt tokens, one cache position at a time,
-    // on ONE row per audio (all beams of an audio are identical until the first selection).
-    for (int p = 0; p < S; ++p) {
-        StepParams* sp = st.sp_h();
-        sp->cache_pos = p; sp->pos_idx = p; sp->parity = 0; sp->first_step = 1;
-        sp->want_no_speech = (p == sot_idx) ? 1 : 0; sp->n_rows = n_audio;
-        for (int a = 0; a < n_audio; ++a) { st.tokens_h()[a] = (int)initial_token(a, p); st.src_h()[a] = a; st.tsmode_h()[a] = 0; }
-        upload_step(n_audio);
-        const bool last = (p == S - 1);
-        const bool want_logits = last || p == sot_idx;
-        m->decoder_step(st, n_audio, G, 1, false, want_logits);
-        if (want_logits) {
-            launch_filter_topk(st.logits.as<float>(), n_audio, cfg, st.sp_d(), st.tsmode_d(), k, st.topk_lp_d(), st.topk_id_d(),
-                               st.no_speech_d(), nullptr, s);
-            HIP_CHECK(hipStreamSynchronize(s));
-            if (p == sot_idx)
-                for (int a = 0; a < n_audio; ++a) no_speech[a] = (double)st.no_speech_h()[a];  // decode/mod.rs:250-255
-        } else {
-            // the pinned step-parameter block is rewritten for the next position: its async H2D copy must have run
-            HIP_CHECK(hipStreamSynchronize(s));
-        }
-    }
+    // ---- forward pass i = 0 (decode/mod.rs:234-245): the S prompt tokens on ONE row per audio (all beams of an audio are
+    // identical until the first selection)
+    prefill(n_audio, no_speech.data());
     if (m->timer && m->timer->enabled) { HIP_CHECK(hipStreamSynchronize(s)); m->timer->collect(); }
     t_prefill_ms = now_ms() - tA;
 
@@ -572,20 +608,11 @@ void DecodeTask::run_forced(int n_audio, int n_steps, const int32_t* ftok, const
     launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m->n_ctx, m->n_ctx, st.r_cap, G, s);
     const FilterCfg cfg = filter_cfg();
     rows.assign(R, initial_tokens);
-    for (int p = 0; p < S; ++p) {
-        StepParams* sp = st.sp_h();
-        sp->cache_pos = p; sp->pos_idx = p; sp->parity = 0; sp->first_step = 1;
-        sp->want_no_speech = (p == sot_idx) ? 1 : 0; sp->n_rows = n_audio;
-        for (int a = 0; a < n_audio; ++a) { st.tokens_h()[a] = (int)initial_tokens[p]; st.src_h()[a] = a; st.tsmode_h()[a] = 0; }
-        upload_step(n_audio);
-        const bool want_logits = (p == S - 1) || p == sot_idx;
-        m->decoder_step(st, n_audio, G, 1, false, want_logits);
-        if (want_logits)
-            launch_filter_topk(st.logits.as<float>(), n_audio, cfg, st.sp_d(), st.tsmode_d(), k, st.topk_lp_d(), st.topk_id_d(),
-                               st.no_speech_d(), nullptr, s);
-        HIP_CHECK(hipStreamSynchronize(s));
-        if (p == sot_idx && out_no_speech)
-            for (int a = 0; a < n_audio; ++a) out_no_speech[a] = (double)st.no_speech_h()[a];
+    {
+        std::vector<double> ns(n_audio, NAN);
+        prefill(n_audio, ns.data());
+        if (out_no_speech)
+            for (int a = 0; a < n_audio; ++a) out_no_speech[a] = ns[a];
     }
     for (int r = 0; r < R; ++r)
         for (int c = 0; c < k; ++c) {

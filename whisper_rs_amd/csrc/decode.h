@@ -104,6 +104,7 @@ struct DecodeTask {
     void run_forced(int n_audio, int n_steps, const int32_t* ftok, const int32_t* fsrc, float* out_lp, int32_t* out_id,
                     double* out_no_speech, bool have_features = false);
 
+    void prefill(int n_audio, double* no_speech_out);  // first forward pass: prompt tokens, step-0 candidates, no-speech
     void upload_step(int rows_n);
     void step_decode(int rows_n);  // decoder_step + filter_topk for rows_n = n_audio*group rows (graph-replayed)
     bool update_beam(int n_audio, bool step0, const float* lp, const int* id);

@@ -331,6 +331,96 @@ void launch_embed_ln(const half_t* emb, const float* pos, const StepParams* sp, 
     }
 }
 
+// ------------------------------------------------------------------------------------------ prompt prefill
+// The decoder's first forward pass takes all sample_begin prompt tokens at once (reference decode/mod.rs:236-245,
+// model.rs:503-506).  Rows are (audio, position): row = a * S + p.  x = emb[token] + pos[p] (fp32), xn = LN(x) fp16 row-major.
+template <int NV>
+__global__ __launch_bounds__(256) void prefill_embed_ln_kernel(const half_t* __restrict__ emb, const float* __restrict__ pos,
+                                                               const int* __restrict__ tokens, int S, int pos0, const float* __restrict__ g,
+                                                               const float* __restrict__ b, int M, int D, float* __restrict__ x,
+                                                               half_t* __restrict__ xn) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int tok = tokens[row];
+    const int pidx = pos0 + row % S;
+    floatx4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const half4 e = *reinterpret_cast<const half4*>(emb + (int64_t)tok * D + c);
+            const floatx4 pp = *reinterpret_cast<const floatx4*>(pos + (int64_t)pidx * D + c);
+            floatx4 a = floatx4{(float)e[0], (float)e[1], (float)e[2], (float)e[3]} + pp;
+            *reinterpret_cast<floatx4*>(x + (int64_t)row * D + c) = a;
+            v[i] = a;
+        } else {
+            v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    ln_row<NV>(v, D, lane, g, b, xn + (int64_t)row * D, nullptr);
+}
+void launch_prefill_embed_ln(const half_t* emb, const float* pos, const int* tokens, int S, int pos0, const float* g, const float* b,
+                             int M, int D, float* x, half_t* xn, hipStream_t s) {
+    const unsigned grid = (unsigned)cdiv(M, 4);
+    switch (ln_nv(D)) {
+#define WRS_PEMB(NV) case NV: prefill_embed_ln_kernel<NV><<<grid, 256, 0, s>>>(emb, pos, tokens, S, pos0, g, b, M, D, x, xn); break;
+        WRS_PEMB(1) WRS_PEMB(2) WRS_PEMB(3) WRS_PEMB(4) WRS_PEMB(5)
+#undef WRS_PEMB
+        default: prefill_embed_ln_kernel<8><<<grid, 256, 0, s>>>(emb, pos, tokens, S, pos0, g, b, M, D, x, xn); break;
+    }
+}
+
+// k / v of the prompt positions (columns D..3D of qkv [n_audio*S, 3D] fp16) into the decode cache
+// [phys_row = a * phys_mul][n_ctx][D] at positions pos0 .. pos0+S-1 (Cached::forward's concatenation, model.rs:83-87)
+__global__ void prefill_store_kv_kernel(const half_t* __restrict__ qkv, int S, int pos0, int D, int n_ctx, int phys_mul, int64_t total8,
+                                        half_t* __restrict__ kc, half_t* __restrict__ vc) {
+    const int d8 = D >> 3;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / d8;
+        const int c = (int)(i % d8) * 8;
+        const int a = (int)(row / S), p = (int)(row % S);
+        const int64_t dst = ((int64_t)a * phys_mul * n_ctx + pos0 + p) * D + c;
+        *reinterpret_cast<half8*>(kc + dst) = *reinterpret_cast<const half8*>(qkv + row * 3 * D + D + c);
+        *reinterpret_cast<half8*>(vc + dst) = *reinterpret_cast<const half8*>(qkv + row * 3 * D + 2 * D + c);
+    }
+}
+void launch_prefill_store_kv(const half_t* qkv, int n_audio, int S, int pos0, int D, int n_ctx, int phys_mul, half_t* kc, half_t* vc,
+                             hipStream_t s) {
+    WRS_REQUIRE(D % 8 == 0 && pos0 >= 0 && pos0 + S <= n_ctx, "prefill_store_kv: bad shape");
+    const int64_t total8 = (int64_t)n_audio * S * (D / 8);
+    prefill_store_kv_kernel<<<(unsigned)std::min<int64_t>(cdiv(total8, 256), 4096), 256, 0, s>>>(qkv, S, pos0, D, n_ctx, phys_mul, total8, kc, vc);
+}
+
+// xn[r] (PACKED activation order, decode-step layout) = LN(x[r * row_stride + row_off]) for r < n: picks one prompt
+// position per audio (sot_idx / the last one) for the logits (decode/mod.rs:250-258)
+template <int NV>
+__global__ __launch_bounds__(256) void gather_ln_packed_kernel(const float* __restrict__ x, int64_t row_stride, int64_t row_off,
+                                                               const float* __restrict__ g, const float* __restrict__ b, int n, int D,
+                                                               half_t* __restrict__ xn) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float* src = x + ((int64_t)r * row_stride + row_off) * D;
+    floatx4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < D ? *reinterpret_cast<const floatx4*>(src + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    ln_row<NV>(v, D, lane, g, b, xn, nullptr, r);
+}
+void launch_gather_ln_packed(const float* x, int64_t row_stride, int64_t row_off, const float* g, const float* b, int n, int D, half_t* xn,
+                             hipStream_t s) {
+    const unsigned grid = (unsigned)cdiv(n, 4);
+    switch (ln_nv(D)) {
+#define WRS_GLN(NV) case NV: gather_ln_packed_kernel<NV><<<grid, 256, 0, s>>>(x, row_stride, row_off, g, b, n, D, xn); break;
+        WRS_GLN(1) WRS_GLN(2) WRS_GLN(3) WRS_GLN(4) WRS_GLN(5)
+#undef WRS_GLN
+        default: gather_ln_packed_kernel<8><<<grid, 256, 0, s>>>(x, row_stride, row_off, g, b, n, D, xn); break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ beam ancestry
 // Replaces `Cached::update_cache` (reference model.rs:53-62: cache.index([src]) gathers every K/V
 // tensor of every block each step).  Instead of moving K/V, each row keeps, per cached position, the

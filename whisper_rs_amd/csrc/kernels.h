@@ -164,6 +164,14 @@ void launch_finish_act(const float* slab, int ksplit, int m_pad, const float* bi
 void launch_embed_ln(const half_t* emb, const float* pos, const StepParams* sp, const int* tokens, const float* g,
                      const float* b, int M, int D, float* x, half_t* xn, hipStream_t s);
 
+// prompt prefill (all sample_begin tokens in one pass, decode/mod.rs:236-245): rows are (audio, position) = a * S + p
+void launch_prefill_embed_ln(const half_t* emb, const float* pos, const int* tokens, int S, int pos0, const float* g, const float* b,
+                             int M, int D, float* x, half_t* xn, hipStream_t s);
+void launch_prefill_store_kv(const half_t* qkv, int n_audio, int S, int pos0, int D, int n_ctx, int phys_mul, half_t* kc, half_t* vc,
+                             hipStream_t s);
+void launch_gather_ln_packed(const float* x, int64_t row_stride, int64_t row_off, const float* g, const float* b, int n, int D, half_t* xn,
+                             hipStream_t s);
+
 // ---------------------------------------------------------------- attention
 // packed K/V for one (batch, head): Kp [Tp/16][2][64][8], Vp [Tp/32][4][64][8] (Tp = round_up(T, 32))
 size_t packed_kv_halfs_per_head(int T);
@@ -171,8 +179,9 @@ size_t packed_kv_halfs_per_head(int T);
 void launch_pack_kv(const half_t* src, int64_t ld, int64_t k_off, int64_t v_off, int n_batch, int T, int H,
                     half_t* kp, half_t* vp, hipStream_t s);
 // encoder-style: every 16-query tile of [n_batch, Tq] attends to all T keys. q [n_batch*Tq, ldq] at col h*64
+// causal: query i attends to keys 0..i (Tq == T): the decoder's prompt prefill
 void launch_attn_full(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_batch, int Tq, int T,
-                      int H, half_t* out, int64_t ldo, hipStream_t s);
+                      int H, half_t* out, int64_t ldo, hipStream_t s, bool causal = false);
 // decode cross-attention: the G (<=16) rows of one audio share that audio's packed K/V; out in PACKED activation
 // order.  Q = (sum_s q_slab[s] + q_bias) * q_scale: the split-K slabs [ksplit][m_pad][H*64] of the query projection.
 void launch_attn_cross(const float* q_slab, int q_ksplit, int q_m_pad, const float* q_bias, float q_scale, const half_t* kp,

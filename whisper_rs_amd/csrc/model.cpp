@@ -595,20 +595,134 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
             launch_finish_residual_ln(st.x.as<float>(), slab, ks_m2, mp, b.mlp2_b, g, bb, rows, D, st.xn.as<half_t>(), stream);
         }
     }
-    if (want_logits) {
-        Timed tm(timer, "dec_gemm_logits", stream, (double)V * D * 2 + (double)rows * V * 4);
-        if (big) {  // tied output projection on the tiled kernel; logits rows padded to st.logits_ld floats
-            GemmA A;
-            A.a = st.xn.as<half_t>(); A.packed = 1; A.packed_rows = st.act_rows;
-            GemmEpi e;
-            e.c = st.logits.p; e.c_f32 = 1; e.ldc = st.logits_ld;
-            launch_gemm_f16(A, emb_p, rows, st.logits_ld, D, e, stream);  // columns >= V come from zero weight rows
-        } else {
-            SkinnyEpi e;
-            e.kind = SK_F32; e.c = st.logits.p; e.ldc = st.logits_ld;
-            launch_gemm_skinny(st.xn.as<half_t>(), emb_p, rows, V, v_pad, D, 1, e, stream);
-        }
+    if (want_logits) decoder_logits(st, rows);
+}
+
+void Model::decoder_logits(DecState& st, int rows) {
+    Timed tm(timer, "dec_gemm_logits", stream, (double)V * D * 2 + (double)rows * V * 4);
+    if (rows >= dec_big_gemm_rows) {  // tied output projection on the tiled kernel; logits rows padded to st.logits_ld floats
+        GemmA A;
+        A.a = st.xn.as<half_t>(); A.packed = 1; A.packed_rows = st.act_rows;
+        GemmEpi e;
+        e.c = st.logits.p; e.c_f32 = 1; e.ldc = st.logits_ld;
+        launch_gemm_f16(A, emb_p, rows, st.logits_ld, D, e, stream);  // columns >= V come from zero weight rows
+    } else {
+        SkinnyEpi e;
+        e.kind = SK_F32; e.c = st.logits.p; e.ldc = st.logits_ld;
+        launch_gemm_skinny(st.xn.as<half_t>(), emb_p, rows, V, v_pad, D, 1, e, stream);
     }
+}
+
+// ------------------------------------------------------------------------------------------ prompt prefill
+// All S prompt tokens of every audio in ONE pass (reference decode/mod.rs:236-245): the rows (audio, position) go through
+// the encoder's kernels — row-major fp16 activations, tiled MFMA GEMMs with fused bias / scale / GELU / residual
+// epilogues — with a causal self-attention (model.rs:191-201) whose K/V also land in the decode cache, and the
+// encoder-style full attention over the audio's packed cross K/V.  (Round 1 fed the prompt one token at a time: ~2.5 ms per
+// token on large-v2, which doubled the latency of every window after the first with condition_on_prev_text.)
+void Model::decoder_prefill(DecState& st, int n_audio, int S, int pos0, int phys_mul, const int* tokens_host, bool all_logits) {
+    WRS_REQUIRE(finalized && !parity_f32, "decoder_prefill: not available in this mode");
+    WRS_REQUIRE(n_audio >= 1 && n_audio <= st.n_audio && S >= 1 && pos0 >= 0 && pos0 + S <= n_ctx, "decoder_prefill: bad shape (%d audios, %d tokens at %d)", n_audio, S, pos0);
+    WRS_REQUIRE((int64_t)(n_audio - 1) * phys_mul < st.r_cap, "decoder_prefill: physical row out of range");
+    WRS_REQUIRE(pos0 == 0, "decoder_prefill: a non-empty cache is not supported (causal attention over cached + new positions)");
+    PrefillWorkspace& w = st.prefill;
+    const int64_t M = (int64_t)n_audio * S;
+    if (M > w.cap_rows || n_audio > w.cap_audio || S > w.cap_s) {
+        const int64_t rows = std::max<int64_t>(M, w.cap_rows);
+        const int na = std::max(n_audio, w.cap_audio), ss = std::max(S, w.cap_s);
+        const int64_t r = std::max<int64_t>(rows, (int64_t)na * ss);
+        w.tokens.alloc((size_t)r * 4);
+        w.x.alloc((size_t)r * D * 4);
+        w.xn.alloc(((size_t)r * D + 4096) * 2);       // tiled GEMMs may over-read up to one tile of rows: clamped in-kernel, padding for K tails
+        w.qkv.alloc((size_t)r * 3 * D * 2);
+        w.kp.alloc((size_t)na * H * packed_kv_halfs_per_head(ss) * 2);
+        w.vp.alloc((size_t)na * H * packed_kv_halfs_per_head(ss) * 2);
+        w.att.alloc(((size_t)r * D + 4096) * 2);
+        w.h.alloc(((size_t)r * 4 * D + 4096) * 2);
+        w.cap_rows = r; w.cap_audio = na; w.cap_s = ss;
+    }
+    if (all_logits) w.logits_all.ensure((size_t)M * st.logits_ld * 4);
+    const float scale = std::pow((float)(D / H), -0.25f);
+    const size_t kv_layer = (size_t)st.r_cap * n_ctx * D;
+    const size_t cross_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
+    HIP_CHECK(hipMemcpyAsync(w.tokens.p, tokens_host, (size_t)M * 4, hipMemcpyHostToDevice, stream));
+    float* x = w.x.as<float>();
+    {
+        Timed tm(timer, "pre_embed_ln", stream);
+        launch_prefill_embed_ln(emb16, dec_pos, w.tokens.as<int>(), S, pos0, dec[0].attn_ln_g, dec[0].attn_ln_b, (int)M, D, x, w.xn.as<half_t>(), stream);
+    }
+    for (int l = 0; l < L_dec; ++l) {
+        const BlockW& b = dec[l];
+        {   // x + attn(attn_ln(x), mask)   (model.rs:302-305)
+            Timed tm(timer, "pre_gemm", stream);
+            GemmA A{w.xn.as<half_t>(), D};
+            GemmEpi e;
+            e.bias = b.qkv_b; e.scale = scale; e.scale_n_end = 2 * D; e.c = w.qkv.p; e.ldc = 3 * D;
+            launch_gemm_f16(A, b.qkv_w, M, 3 * D, D, e, stream);
+        }
+        {
+            Timed tm(timer, "pre_attn_self", stream);
+            launch_prefill_store_kv(w.qkv.as<half_t>(), n_audio, S, pos0, D, n_ctx, phys_mul, st.kc.as<half_t>() + l * kv_layer,
+                                    st.vc.as<half_t>() + l * kv_layer, stream);
+            launch_pack_kv(w.qkv.as<half_t>(), 3 * D, D, 2 * D, n_audio, S, H, w.kp.as<half_t>(), w.vp.as<half_t>(), stream);
+            launch_attn_full(w.qkv.as<half_t>(), 3 * D, w.kp.as<half_t>(), w.vp.as<half_t>(), n_audio, S, S, H, w.att.as<half_t>(), D, stream, true);
+        }
+        {
+            Timed tm(timer, "pre_gemm", stream);
+            GemmA A{w.att.as<half_t>(), D};
+            GemmEpi e;
+            e.bias = b.out_b; e.residual = x; e.c = x; e.c_f32 = 1; e.ldc = D;
+            launch_gemm_f16(A, b.out_w, M, D, D, e, stream);
+        }
+        launch_layernorm(x, b.cross_ln_g, b.cross_ln_b, M, D, w.xn.as<half_t>(), nullptr, stream);
+        {   // + cross_attn(cross_attn_ln(x), xa)   (model.rs:309-310): every prompt position attends to the audio's 1500 keys
+            Timed tm(timer, "pre_gemm", stream);
+            GemmA A{w.xn.as<half_t>(), D};
+            GemmEpi e;
+            e.bias = b.cq_b; e.scale = scale; e.scale_n_end = D; e.c = w.qkv.p; e.ldc = D;
+            launch_gemm_f16(A, b.cq_w, M, D, D, e, stream);
+        }
+        {
+            Timed tm(timer, "pre_attn_cross", stream);
+            launch_attn_full(w.qkv.as<half_t>(), D, st.ckp(st.cross_sel) + l * cross_layer, st.cvp(st.cross_sel) + l * cross_layer, n_audio, S, T, H,
+                             w.att.as<half_t>(), D, stream);
+        }
+        {
+            Timed tm(timer, "pre_gemm", stream);
+            GemmA A{w.att.as<half_t>(), D};
+            GemmEpi e;
+            e.bias = b.cout_b; e.residual = x; e.c = x; e.c_f32 = 1; e.ldc = D;
+            launch_gemm_f16(A, b.cout_w, M, D, D, e, stream);
+        }
+        launch_layernorm(x, b.mlp_ln_g, b.mlp_ln_b, M, D, w.xn.as<half_t>(), nullptr, stream);
+        {   // + mlp(mlp_ln(x))   (model.rs:315)
+            Timed tm(timer, "pre_gemm", stream);
+            GemmA A{w.xn.as<half_t>(), D};
+            GemmEpi e;
+            e.bias = b.mlp0_b; e.act = 1; e.c = w.h.p; e.ldc = 4 * D;
+            launch_gemm_f16(A, b.mlp0_w, M, 4 * D, D, e, stream);
+        }
+        {
+            Timed tm(timer, "pre_gemm", stream);
+            GemmA A{w.h.as<half_t>(), 4 * (int64_t)D};
+            GemmEpi e;
+            e.bias = b.mlp2_b; e.residual = x; e.c = x; e.c_f32 = 1; e.ldc = D;
+            launch_gemm_f16(A, b.mlp2_w, M, D, 4 * D, e, stream);
+        }
+        if (l + 1 < L_dec) launch_layernorm(x, dec[l + 1].attn_ln_g, dec[l + 1].attn_ln_b, M, D, w.xn.as<half_t>(), nullptr, stream);
+    }
+    if (all_logits) {  // stage API: logits of every position (TextDecoder::forward_ext returns [B, S, V])
+        launch_layernorm(x, ln_g, ln_b, M, D, w.xn.as<half_t>(), nullptr, stream);
+        GemmA A{w.xn.as<half_t>(), D};
+        GemmEpi e;
+        e.c = w.logits_all.p; e.c_f32 = 1; e.ldc = st.logits_ld;
+        launch_gemm_f16(A, emb_p, M, st.logits_ld, D, e, stream);
+    }
+}
+
+void Model::prefill_logits(DecState& st, int n_audio, int S, int p) {
+    WRS_REQUIRE(p >= 0 && p < S && n_audio >= 1 && (int64_t)n_audio * S <= st.prefill.cap_rows, "prefill_logits: bad position %d of %d", p, S);
+    launch_gather_ln_packed(st.prefill.x.as<float>(), S, p, ln_g, ln_b, n_audio, D, st.xn.as<half_t>(), stream);
+    decoder_logits(st, n_audio);
 }
 
 }  // namespace wrs

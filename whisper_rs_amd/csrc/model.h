@@ -47,6 +47,13 @@ struct EncoderWorkspace {
     DevBuf mel_t, c1, x, xn, qkv, kp, vp, att, h, xa16, xa32;
 };
 
+// workspace of the batched prompt prefill (Model::decoder_prefill): rows are (audio, prompt position)
+struct PrefillWorkspace {
+    int64_t cap_rows = 0;
+    int cap_audio = 0, cap_s = 0;
+    DevBuf tokens, x, xn, qkv, kp, vp, att, h, logits_all;
+};
+
 // decoder K/V caches + per-step scratch for up to `a_cap` audios x `group` rows
 struct DecState {
     int a_cap = 0, group = 1, r_cap = 0, m_pad = 0, act_rows = 0, logits_ld = 0;
@@ -63,6 +70,7 @@ struct DecState {
     DevBuf anc;                 // [2][r_cap][n_ctx]
     DevBuf x, xn, att, h, slab, logits, ckv_tmp;
     std::unique_ptr<DecStateF32> f32;  // f32 parity mode only
+    PrefillWorkspace prefill;   // allocated on first use
     DevBuf sp_dev;              // StepParams + tokens[r_cap] + src[r_cap] + ts_mode[r_cap]
     PinnedBuf sp_host;
     PinnedBuf topk;             // lp [r_cap*8] f32 | id [r_cap*8] i32 | no_speech [r_cap] f32
@@ -166,6 +174,15 @@ struct Model {
     // one token per row. rows = logical rows this step; phys_mul = physical cache-row stride per logical row;
     // q_per_audio = rows sharing one audio's cross K/V.  Step scalars / tokens / src must already be in st.sp_dev.
     void decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits);
+    // tied output projection of st.xn (packed activations, `rows` rows) into st.logits (model.rs:521)
+    void decoder_logits(DecState& st, int rows);
+    // The decoder's first forward pass: all S prompt tokens of every audio at once (reference decode/mod.rs:236-245,
+    // TextDecoder::forward_ext with the causal mask, model.rs:191-201,490-522).  tokens_host [n_audio][S]; positions
+    // pos0 .. pos0+S-1 of physical row a * phys_mul of the self-attention K/V cache are written.  Afterwards
+    // prefill_logits(st, n_audio, S, p) puts the logits of prompt position p of every audio into st.logits rows 0..n_audio-1;
+    // logits_all (optional, device [n_audio*S, logits_ld] fp32) receives every position's logits (stage API).
+    void decoder_prefill(DecState& st, int n_audio, int S, int pos0, int phys_mul, const int* tokens_host, bool all_logits);
+    void prefill_logits(DecState& st, int n_audio, int S, int p);
 };
 
 // log-mel on device (reference audio.rs:230-259).  audio_d [n_batch, n] f32 device -> out_d [n_batch, 80, n/160] f32 device

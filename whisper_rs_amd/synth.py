@@ -118,15 +118,18 @@ def make_weights(dims: ModelDims, seed=0, emb_gain=1.0, force_eot_after=None):
     return w
 
 
-def make_audio(n_windows=1, seed=1234, n_samples=N_SAMPLES):
+def make_audio(n_windows=1, seed=1234, n_samples=N_SAMPLES, index0=0):
     """[n_windows, n_samples] float32: 0.1*N(0,1) + two sines (220 Hz, 1 kHz; amp 0.2)
-    with a slow per-window amplitude envelope so the log-mel is not flat."""
+    with a slow per-window amplitude envelope so the log-mel is not flat.
+    index0: position of the first window in a longer recording — make_audio(n, seed + k, index0=k) are exactly windows
+    k .. k+n-1 of make_audio(k + n, seed) (ranks of a sharded job generate only their own windows)."""
     t = np.arange(n_samples, dtype=np.float64) / SAMPLE_RATE
     out = np.empty((n_windows, n_samples), dtype=np.float32)
-    for i in range(n_windows):
-        g = _rng(seed + i, "audio")
+    for j in range(n_windows):
+        i = index0 + j
+        g = _rng(seed + j, "audio")
         noise = (0.05 + 0.03 * (i % 5)) * g.standard_normal(n_samples, dtype=np.float32)
         f1, f2 = 150.0 + 97.0 * (i % 13), 700.0 + 310.0 * (i % 11)  # distinct spectra per window
         env = 0.5 + 0.5 * np.sin(2 * np.pi * (0.2 + 0.05 * (i % 7)) * t)
-        out[i] = noise + (0.2 * env * (np.sin(2 * np.pi * f1 * t) + np.sin(2 * np.pi * f2 * t))).astype(np.float32)
+        out[j] = noise + (0.2 * env * (np.sin(2 * np.pi * f1 * t) + np.sin(2 * np.pi * f2 * t))).astype(np.float32)
     return out
