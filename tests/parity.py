@@ -182,7 +182,7 @@ def run_with_resync(case, task, mel, view, G, eot, exact=False, cand_tol=CAND_ER
     raise AssertionError(f"{case}: more than {MAX_RESYNC} near-tie splits: {splits}")
 
 
-def teacher_forced_check(case, glp, gid, gns, view, G, eot, min_exact_frac):
+def teacher_forced_check(case, glp, gid, gns, view, G, eot, min_exact_frac, cand_tol=CAND_ERR):
     """Every step of a teacher-forced device run (glp/gid [steps, rows, k] produced while following the oracle's
     decisions) against the oracle: candidate log-probs within CAND_ERR, and the selection the reference algorithm makes
     from the device's candidates equals the oracle's unless it is an explained near-tie."""
@@ -194,7 +194,7 @@ def teacher_forced_check(case, glp, gid, gns, view, G, eot, min_exact_frac):
     worst, splits = 0.0, []
     for s in range(steps):
         olp_full = view.olp(s)
-        worst = max(worst, check_candidates(glp[s], gid[s], olp_full, s))
+        worst = max(worst, check_candidates(glp[s], gid[s], olp_full, s, cand_tol))
         work = slp.clone()
         nt, src, _ = OD.beam_select(rows, work, torch.from_numpy(glp[s]), torch.from_numpy(gid[s].astype(np.int64)), G, eot)
         sel_tok, sel_src = np.array([t[-1] for t in nt]), np.array(src)

@@ -151,7 +151,8 @@ def test_capacity_and_errors(gpu):
 # ------------------------------------------------------------------------------------------------
 # Teacher-forced verification: the device follows the ORACLE's beam decisions at every step, so every step of a long
 # decode is checked in ONE device run (the free-running comparison above re-runs the device after each near-tie).
-def _teacher_forced_check(gpu, dims_name, n_audio, sample_len, min_exact_frac, feats=None, ids=None, okw=None, gkw=None, **wkw):
+def _teacher_forced_check(gpu, dims_name, n_audio, sample_len, min_exact_frac, feats=None, ids=None, okw=None, gkw=None, cand_tol=P.CAND_ERR,
+                          f32_mode=False, **wkw):
     """feats: encoder outputs [n_audio, 1500, D] (decoder-only run through wrs_debug_decode_forced_features) instead of
     the synthetic mel windows.  okw / gkw: extra oracle / device decode options."""
     ids = ids or TokenIds.for_vocab(MODEL_DIMS[dims_name].n_vocab)
@@ -165,14 +166,20 @@ def _teacher_forced_check(gpu, dims_name, n_audio, sample_len, min_exact_frac, f
         else:
             oouts = ot.run_from_features(torch.from_numpy(feats))
     view = P.OracleView.from_task(ot, oouts, 5)
-    gm = gpu_model(gpu, dims_name, **wkw)
+    if f32_mode:
+        from helpers import weights
+        gm = DBG.parity_f32_model(MODEL_DIMS[dims_name], weights(dims_name, 0, **wkw))
+    else:
+        gm = gpu_model(gpu, dims_name, **wkw)
     task = gpu.DecodeTask(gm, ids, gpu.DecodeOptions(sample_len=sample_len, max_audio=n_audio, **(gkw or {})))
     if feats is None:
         glp, gid, gns = task.run_forced(mel, view.tok, view.src)
     else:
         glp, gid, gns = DBG.decode_forced_features(task, feats, view.tok, view.src)
     task.close()
-    exact, steps, _ = P.teacher_forced_check(f"{dims_name}_tf_x{n_audio}", glp, gid, gns, view, 5, ids.eot, min_exact_frac)
+    if f32_mode:
+        gm.close()
+    exact, steps, _ = P.teacher_forced_check(f"{dims_name}_tf_x{n_audio}{'_f32' if f32_mode else ''}", glp, gid, gns, view, 5, ids.eot, min_exact_frac, cand_tol)
     return exact, steps
 
 

@@ -16,70 +16,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------ mel
-// reference audio.rs:236-246: stft(center=true, pad_mode="reflect") pads n_fft/2 = 200 samples each side.
-__global__ void reflect_pad_kernel(const float* __restrict__ audio, int64_t n, float* __restrict__ out, int64_t out_stride) {
-    const int64_t b = blockIdx.y;
-    const float* src = audio + b * n;
-    float* dst = out + b * out_stride;
-    const int64_t total = n + 400;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < out_stride; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        if (i < total) {
-            int64_t j = i - 200;
-            if (j < 0) j = -j;
-            else if (j >= n) j = 2 * (n - 1) - j;
-            v = src[j];
-        }
-        dst[i] = v;
-    }
-}
-void launch_reflect_pad(const float* audio, int64_t n_batch, int64_t n, float* out, int64_t out_stride, hipStream_t s) {
-    dim3 grid((unsigned)std::min<int64_t>(cdiv(out_stride, 256), 2048), (unsigned)n_batch);
-    reflect_pad_kernel<<<grid, 256, 0, s>>>(audio, n, out, out_stride);
-}
-
-__global__ void fill_f32_kernel(float* p, float v, int64_t n) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
-}
-void launch_fill_f32(float* p, float v, int64_t n, hipStream_t s) {
-    fill_f32_kernel<<<(int)std::min<int64_t>(cdiv(n, 256), 2048), 256, 0, s>>>(p, v, n);
-}
-
-__device__ __forceinline__ float key_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
-
-// reference audio.rs:256-258: floor at (global max - 8), then (x + 4) / 4; output in the reference's [80, F] layout.
-// 32x32 LDS transpose tile: reads time-major rows (coalesced over mel bins), writes frame-contiguous rows.
-__global__ void mel_finalize_kernel(const float* __restrict__ logmel, const int* __restrict__ maxkey, int64_t n_frames,
-                                    float* __restrict__ out) {
-    __shared__ float tile[32][33];
-    const int64_t b = blockIdx.z;
-    const int64_t f0 = (int64_t)blockIdx.x * 32;
-    const int c0 = blockIdx.y * 32;
-    const float floor_v = key_to_float(maxkey[b]) - 8.0f;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
-    for (int r = ty; r < 32; r += 8) {
-        const int64_t f = f0 + r;
-        const int c = c0 + tx;
-        float v = 0.f;
-        if (f < n_frames && c < 80) v = logmel[(b * n_frames + f) * 80 + c];
-        tile[r][tx] = v;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int c = c0 + r;
-        const int64_t f = f0 + tx;
-        if (f < n_frames && c < 80) {
-            const float v = fmaxf(tile[tx][r], floor_v);
-            out[(b * 80 + c) * n_frames + f] = (v + 4.0f) / 4.0f;
-        }
-    }
-}
-void launch_mel_finalize(const float* logmel, const float* maxbuf, int64_t n_batch, int64_t n_frames, float* out,
-                         hipStream_t s) {
-    dim3 grid((unsigned)cdiv(n_frames, 32), 3, (unsigned)n_batch);
-    mel_finalize_kernel<<<grid, 256, 0, s>>>(logmel, reinterpret_cast<const int*>(maxbuf), n_frames, out);
-}
-
 // reference transcribe.rs:152 + audio.rs:213-228 (pad_or_trim of mel[:, seek:]) fused with the layout change the
 // conv1 implicit GEMM wants: [3002, 80] fp16 time-major, rows 0 and 3001 zero (conv padding=1).
 __global__ void mel_prep_kernel(const float* __restrict__ mel, int64_t n_frames, int64_t mel_bs, int64_t seek,

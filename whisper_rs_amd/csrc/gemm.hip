@@ -1121,19 +1121,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
 }
 
-void launch_gemm_f32(const float* a, int64_t lda, int64_t rows_per_batch, int64_t batch_stride, const float* w,
-                     int64_t ldw, int64_t M, int64_t N, int64_t K, int mode, float* c, int64_t ldc, float* maxbuf,
-                     hipStream_t s) {
-    WRS_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldw % 4 == 0 && batch_stride % 4 == 0, "gemm_f32: alignment");
-    WRS_REQUIRE(M > 0 && M < (1ll << 31), "gemm_f32: bad M");
-    dim3 grid((unsigned)cdiv(M, 64), (unsigned)cdiv(N, 64));
-    if (mode == 0)
-        gemm_f32_kernel<0><<<grid, 256, 0, s>>>(a, lda, rows_per_batch, batch_stride, w, ldw, (int)M, (int)N, (int)K, c, ldc, nullptr);
-    else
-        gemm_f32_kernel<1><<<grid, 256, 0, s>>>(a, lda, rows_per_batch, batch_stride, w, ldw, (int)M, (int)N, (int)K, c, ldc,
-                                                reinterpret_cast<int*>(maxbuf));
-}
-
 void launch_gemm_f32_epi(const float* a, int64_t lda, int64_t rows_per_batch, int64_t batch_stride, const float* w, int64_t ldw,
                          int64_t M, int64_t N, int64_t K, const GemmF32Epi& e, hipStream_t s) {
     WRS_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldw % 4 == 0 && batch_stride % 4 == 0, "gemm_f32: alignment");

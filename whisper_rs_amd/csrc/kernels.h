@@ -116,13 +116,7 @@ int skinny_m_pad(int M);
 int gemm_dec_plan(int M, int64_t N, int64_t K, int* kps_out, int* mt_block_out);
 void launch_gemm_dec(const half_t* a, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K, float* slab, hipStream_t s);
 
-// ---------------------------------------------------------------- f32 GEMM (STFT, mel filterbank)
-// mode 0: power spectrum. C[m][n/2] = acc[2b]^2 + acc[2b+1]^2 (interleaved re/im columns), ldc floats
-// mode 1: log-mel.        C[m][n] = log10(max(acc, 1e-10)); atomic max per batch into maxbuf[m / rows_per_batch]
-void launch_gemm_f32(const float* a, int64_t lda, int64_t rows_per_batch, int64_t batch_stride, const float* w,
-                     int64_t ldw, int64_t M, int64_t N, int64_t K, int mode, float* c, int64_t ldc, float* maxbuf,
-                     hipStream_t s);
-
+// ---------------------------------------------------------------- f32 GEMM (f32 parity mode)
 // mode 2 (f32 parity mode, parity_f32.hip): C[crow(m)][n] = act((acc + bias[n]) * (n < scale_n_end ? scale : 1)) + posemb + residual
 struct GemmF32Epi {
     const float* bias = nullptr;
@@ -140,11 +134,13 @@ void launch_gemm_f32_epi(const float* a, int64_t lda, int64_t rows_per_batch, in
                          int64_t M, int64_t N, int64_t K, const GemmF32Epi& epi, hipStream_t s);
 
 // ---------------------------------------------------------------- mel
-void launch_reflect_pad(const float* audio, int64_t n_batch, int64_t n, float* out, int64_t out_stride, hipStream_t s);
-void launch_fill_f32(float* p, float v, int64_t n, hipStream_t s);
-// logmel [B*F, 80] (time-major, log10 domain) -> out [B, 80, F] = (max(x, max_b - 8) + 4) / 4
-void launch_mel_finalize(const float* logmel, const float* maxbuf, int64_t n_batch, int64_t n_frames, float* out,
-                         hipStream_t s);
+// fused log-mel (mel_fused.hip): audio [n_batch, n] f32 -> out [n_batch, 80, n/160] f32, reference audio.rs:230-259.
+// twp: DFT matrix packed by mel_pack_twiddle; filt [80][201]; krange [80][2] non-zero band per filter row; maxkey [n_batch]
+// preset to the key of a very negative float (0x80808080).
+size_t mel_twiddle_packed_floats();
+void mel_pack_twiddle(float* out);
+void launch_mel_fused(const float* audio, int64_t n_batch, int64_t n, const float* twp, const float* filt, const int* krange, float* out,
+                      int* maxkey, hipStream_t s);
 // mel [B, 80, F] f32 -> encoder input [B, 3002, 80] fp16 (time-major, one zero row each side), frames
 // seek..seek+3000, zero (0.0 in log-mel space, reference audio.rs:226) past the end
 void launch_mel_prep(const float* mel, int64_t n_batch, int64_t n_frames, int64_t mel_batch_stride, int64_t seek,

@@ -1,8 +1,5 @@
-// log-mel front-end on device: reference src/audio.rs:175-188 (mel_filter), :230-259
-// (log_mel_spectrogram).  STFT = reflect pad + [frames x 400] x [400 x 402] exact-f32 MFMA GEMM
-// against a Hann-windowed DFT matrix (frames are overlapping rows of the padded signal: lda = hop),
-// power in the GEMM epilogue, mel projection as a second f32 GEMM with log10 + per-recording
-// max (atomic) in its epilogue, then one floor/scale/transpose pass.
+// log-mel front-end on device: reference src/audio.rs:175-188 (mel_filter), :230-259 (log_mel_spectrogram).
+// Host side: filterbank, tables; the device work is one fused kernel + an elementwise scale pass (mel_fused.hip).
 #include "model.h"
 #include <cmath>
 
@@ -31,24 +28,15 @@ void mel_filter_host(float* out) {
     }
 }
 
-static const int kPowerLd = 208;  // 201 bins padded to a multiple of 16 (f32 GEMM K granularity)
-
 static void ensure_tables(MelWorkspace& ws, const float* filter_host_or_null) {
     if (!ws.tables_ready) {
-        // DFT matrix rows: 2b = hann[n]*cos(2 pi b n / 400), 2b+1 = -hann[n]*sin(...); rows 402..447 zero
-        std::vector<float> tw((size_t)448 * 400, 0.f);
-        const double two_pi = 6.283185307179586476925286766559;
-        for (int b = 0; b <= 200; ++b)
-            for (int n = 0; n < 400; ++n) {
-                const double win = 0.5 - 0.5 * std::cos(two_pi * n / 400.0);  // periodic Hann (audio.rs:233)
-                const double ang = two_pi * (double)((b * n) % 400) / 400.0;
-                tw[(size_t)(2 * b) * 400 + n] = (float)(win * std::cos(ang));
-                tw[(size_t)(2 * b + 1) * 400 + n] = (float)(-win * std::sin(ang));
-            }
+        std::vector<float> tw(mel_twiddle_packed_floats());
+        mel_pack_twiddle(tw.data());
         ws.twiddle.alloc(tw.size() * 4);
         HIP_CHECK(hipMemcpyAsync(ws.twiddle.p, tw.data(), tw.size() * 4, hipMemcpyHostToDevice, utility_stream()));
         HIP_CHECK(hipStreamSynchronize(utility_stream()));
-        ws.filter.alloc((size_t)128 * kPowerLd * 4);
+        ws.filter.alloc((size_t)80 * 201 * 4);
+        ws.krange.alloc((size_t)80 * 2 * 4);
         ws.tables_ready = true;
         ws.filter_host.clear();
     }
@@ -56,10 +44,16 @@ static void ensure_tables(MelWorkspace& ws, const float* filter_host_or_null) {
     if (filter_host_or_null) memcpy(f.data(), filter_host_or_null, f.size() * 4);
     else mel_filter_host(f.data());
     if (f != ws.filter_host) {
-        std::vector<float> padded((size_t)128 * kPowerLd, 0.f);
-        for (int i = 0; i < 80; ++i)
-            for (int k = 0; k < 201; ++k) padded[(size_t)i * kPowerLd + k] = f[i * 201 + k];
-        HIP_CHECK(hipMemcpyAsync(ws.filter.p, padded.data(), padded.size() * 4, hipMemcpyHostToDevice, utility_stream()));
+        std::vector<int> kr(160);
+        for (int i = 0; i < 80; ++i) {  // band of non-zeros of every filter row (5 bins on average for the Slaney bank; any filter works)
+            int k0 = 201, k1 = 0;
+            for (int k = 0; k < 201; ++k)
+                if (f[i * 201 + k] != 0.f) { k0 = std::min(k0, k); k1 = k + 1; }
+            if (k1 == 0) k0 = 0;
+            kr[2 * i] = k0; kr[2 * i + 1] = k1;
+        }
+        HIP_CHECK(hipMemcpyAsync(ws.filter.p, f.data(), f.size() * 4, hipMemcpyHostToDevice, utility_stream()));
+        HIP_CHECK(hipMemcpyAsync(ws.krange.p, kr.data(), kr.size() * 4, hipMemcpyHostToDevice, utility_stream()));
         HIP_CHECK(hipStreamSynchronize(utility_stream()));
         ws.filter_host = f;
     }
@@ -71,18 +65,9 @@ void log_mel_device(MelWorkspace& ws, const float* audio_d, int64_t n_batch, int
     const int64_t F = n / WRS_HOP_LENGTH;  // 1 + n/160 frames, last one dropped (audio.rs:247)
     WRS_REQUIRE(F >= 1 && n_batch * F < (1ll << 31), "log_mel_spectrogram: bad frame count");
     ensure_tables(ws, filter_host_or_null);
-    const int64_t stride = round_up(n + 400, 4);
-    ws.padded.ensure((size_t)n_batch * stride * 4 + 4096);
-    ws.power.ensure((size_t)n_batch * F * kPowerLd * 4);
-    ws.logmel.ensure((size_t)n_batch * F * 80 * 4);
     ws.maxbuf.ensure((size_t)n_batch * 4);
-    launch_reflect_pad(audio_d, n_batch, n, ws.padded.as<float>(), stride, s);
     HIP_CHECK(hipMemsetAsync(ws.maxbuf.p, 0x80, (size_t)n_batch * 4, s));  // order-key of a very negative float
-    launch_gemm_f32(ws.padded.as<float>(), WRS_HOP_LENGTH, F, stride, ws.twiddle.as<float>(), 400, n_batch * F, 402, 400, 0,
-                    ws.power.as<float>(), kPowerLd, nullptr, s);
-    launch_gemm_f32(ws.power.as<float>(), kPowerLd, F, F * kPowerLd, ws.filter.as<float>(), kPowerLd, n_batch * F, 80, kPowerLd, 1,
-                    ws.logmel.as<float>(), 80, ws.maxbuf.as<float>(), s);
-    launch_mel_finalize(ws.logmel.as<float>(), ws.maxbuf.as<float>(), n_batch, F, out_d, s);
+    launch_mel_fused(audio_d, n_batch, n, ws.twiddle.as<float>(), ws.filter.as<float>(), ws.krange.as<int>(), out_d, ws.maxbuf.as<int>(), s);
 }
 
 }  // namespace wrs

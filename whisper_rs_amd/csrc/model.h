@@ -187,7 +187,7 @@ struct Model {
 
 // log-mel on device (reference audio.rs:230-259).  audio_d [n_batch, n] f32 device -> out_d [n_batch, 80, n/160] f32 device
 struct MelWorkspace {
-    DevBuf padded, power, logmel, maxbuf, twiddle, filter;
+    DevBuf maxbuf, twiddle, filter, krange;
     bool tables_ready = false;
     std::vector<float> filter_host;
 };
