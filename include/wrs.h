@@ -11,7 +11,12 @@
  * Conventions
  *   - every function returns 0 on success, a WRS_E* code otherwise; wrs_last_error() gives
  *     the thread-local message (reference: anyhow::Result / panics; never unwinds here).
- *   - plain pointers and sizes only.  Host pointers unless a parameter says "device".
+ *   - plain pointers and sizes only.  Host pointers unless a parameter says "device" (mem_kind = WRS_MEM_DEVICE).
+ *   - DEVICE INPUTS MUST BE COMPLETE ON ENTRY: the library works on its own non-blocking HIP streams and does not order
+ *     itself against the stream that produced a device buffer.  A caller that fills a device buffer with its own kernels
+ *     or copies (e.g. torch) synchronises that work (hipStreamSynchronize / torch.cuda.synchronize()) before passing the
+ *     pointer, and keeps the buffer unchanged until the call — for wrs_decode_task_encode_async until the matching
+ *     wrs_decode_task_run_pending — has returned.  Device OUTPUTS are complete when a call returns.
  *   - handles are used from one thread at a time (reference types are !Send: Rc/RefCell).
  *   - a task holds a non-owning pointer to its model: the model must outlive its tasks
  *     (reference: DecodeTask<'a> borrows &'a Whisper, decode/mod.rs:24-25).
@@ -235,7 +240,11 @@ int wrs_decode_task_run(wrs_decode_task* t, const float* mel, int32_t n_audio, i
 /* same, starting from encoder output [n_audio, n_audio_ctxs, n_state] f32 (run_inner after :296) */
 int wrs_decode_task_run_features(wrs_decode_task* t, const float* audio_features, int32_t n_audio, int mem_kind,
                                  wrs_decode_result* result);
-/* same, starting from raw audio windows [n_audio, 480000] f32: mel (per-window max) + run. */
+/* same, starting from raw audio windows [n_audio, 480000] f32: log-mel + run.  EVERY WINDOW IS ITS OWN RECORDING here: the
+ * log-mel floor (max - 8, audio.rs:256) uses the window's own maximum.  The reference's long-form loop normalises over the
+ * whole file instead (transcribe.rs:111-112): wrs_transcribe_task_run / _run_chunked do that; this entry, encode_async and
+ * the window pool are for windows that ARE separate recordings, or for callers that accept per-window normalisation
+ * (the two give the same spectrogram unless a window's own maximum differs from the file's). */
 int wrs_decode_task_run_audio(wrs_decode_task* t, const float* audio, int32_t n_audio, int mem_kind,
                               wrs_decode_result* result);
 /* Overlapped mode (beyond the reference, whose loop is sequential: the unit that keeps a GPU's work queue full).
@@ -281,7 +290,9 @@ int wrs_filter_topk(wrs_decode_task* t, const float* logits, const int64_t* toke
  * one worker thread + one decode task per model replica — replicas on different GPUs of the node (create one model per
  * device with wrs_model_create(dims, device_id, ..)), or several replicas on one GPU — and hands out batches of
  * opt->max_audio consecutive windows from a shared queue; every worker keeps its GPU busy in overlapped mode.
- *   audio: [n_windows, 480000] f32, host memory (or device memory when every replica sits on that GPU); result->outputs[w] belongs to window w (same content as
+ *   audio: [n_windows, 480000] f32, host memory (or device memory when every replica sits on that GPU); each window is
+ *   normalised as its own recording (see wrs_decode_task_run_audio; for whole-file normalisation compute the spectrogram
+ *   once with wrs_log_mel_spectrogram and feed windows of it to wrs_decode_task_run); result->outputs[w] belongs to window w (same content as
  *   wrs_decode_task_run_audio on that window); release with wrs_decode_result_free.  The models must outlive the pool and
  *   must not be used elsewhere while a run is in progress. */
 typedef struct wrs_window_pool wrs_window_pool;

@@ -26,7 +26,12 @@ extern "C" {
 #define WRS_GEMM_PATH_TILED 0      /* launch_gemm_f16 */
 #define WRS_GEMM_PATH_DEC 1        /* launch_gemm_dec: decode GEMM for < 480 rows, fp32 split-K slabs */
 #define WRS_GEMM_PATH_SKINNY_F32 2 /* launch_gemm_skinny, fp32 row-major output (logits at < 480 rows) */
-#define WRS_GEMM_PATH_FUSED_LN 3   /* launch_gemm_rowln: decode N = D GEMM with bias + residual + LayerNorm epilogue */
+#define WRS_GEMM_PATH_PRING 3      /* launch_gemm_pring: persistent ring GEMM of the decode step at >= 480 rows (csrc/gemm_pring.hip) */
+/* epilogue modes of the persistent ring GEMM */
+#define WRS_PRING_RESID 0          /* x[m][n] += acc + bias, fp32 in place */
+#define WRS_PRING_F16 1            /* c = fp16((acc + bias) * scale) row-major */
+#define WRS_PRING_GELU_PACKED 2    /* c = fp16(gelu(acc + bias)) in packed-activation order */
+#define WRS_PRING_QKV 3            /* q -> c (fp16 [M, D]), k / v -> caches at cache_pos */
 
 /* C[M, N] = epilogue(A[M, K] * W[N, K]^T) through the library's own weight packer and GEMM launchers.
  * All pointers are DEVICE pointers on device `device_id`; the call synchronises before returning. */
@@ -59,11 +64,13 @@ typedef struct wrs_debug_gemm {
     int64_t ldc, c_rows_per_batch, c_batch_rows, c_row_off;
     int32_t ksplit;          /* tiled path: > 1 = split-K, raw fp32 partial sums [ksplit][slab_stride]; path DEC: out = slabs used */
     int64_t slab_stride;     /* tiled path in; path DEC: out = m_pad * N */
-    /* path FUSED_LN: x[m] = residual_inout[m] + bias + A W^T (fp32, in place), xn = LayerNorm(x) * ln_g + ln_b in packed order */
-    float* x_inout;
-    const float* ln_g;
-    const float* ln_b;
-    void* xn_packed;
+    /* path PRING: epilogue mode, tile rows (64 / 128); RESID updates `c` (fp32 [M, ldc]) in place; QKV writes q to `c`
+     * (fp16 [M, ldc], ldc >= N/3) and k / v to kcache / vcache (fp16 [M * phys_mul][n_ctx][N/3]) at position cache_pos */
+    int32_t pring_mode, pring_bm;
+    void* kcache;
+    void* vcache;
+    int32_t n_ctx, cache_pos, phys_mul;
+    int32_t pring_workgroups; /* out */
 } wrs_debug_gemm;
 int wrs_debug_gemm_f16(wrs_debug_gemm* g);
 
@@ -78,6 +85,7 @@ typedef struct wrs_debug_attn_self {
     void* vc;
     const int32_t* anc;      /* [n_rows][n_ctx]: physical row holding (row, position) */
     void* out_packed;        /* fp16 packed-activation order, round_up(n_rows,128) x D */
+    int32_t q16_mode;        /* 1: the >= 480-row form of the kernel (q as fp16, new k / v already in the cache) */
 } wrs_debug_attn_self;
 int wrs_debug_attn_self_run(wrs_debug_attn_self* a);
 
@@ -92,6 +100,7 @@ typedef struct wrs_debug_attn_cross {
     const void* k;
     const void* v;
     void* out_packed;
+    int32_t q16_mode;        /* 1: the >= 480-row form (query projection given as fp16, bias and scale applied) */
 } wrs_debug_attn_cross;
 int wrs_debug_attn_cross_run(wrs_debug_attn_cross* a);
 

@@ -30,8 +30,9 @@ def _randn(shape, seed, scale=1.0, dtype=torch.float32):
     return (scale * torch.randn(shape, generator=g, device=_dev(), dtype=torch.float32)).to(dtype)
 
 
+@pytest.mark.parametrize("q16_mode", [0, 1], ids=["slab_q", "fp16_q"])
 @pytest.mark.parametrize("n_audio,G", [(256, 5), (3, 1), (7, 5), (2, 16)])
-def test_cross_attention_kernel(gpu, n_audio, G):
+def test_cross_attention_kernel(gpu, n_audio, G, q16_mode):
     H, D, T = 20, 1280, 1500
     R = n_audio * G
     q = _randn((R, D), 1)                      # un-biased query projection (fp32 slab)
@@ -43,7 +44,7 @@ def test_cross_attention_kernel(gpu, n_audio, G):
     a = DBG.DebugAttnCrossC()
     a.device_id, a.n_audio, a.G, a.H, a.D, a.T = 0, n_audio, G, H, D, T
     a.q, a.q_bias, a.q_scale = q.data_ptr(), qb.data_ptr(), scale
-    a.k, a.v, a.out_packed = k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.k, a.v, a.out_packed, a.q16_mode = k.data_ptr(), v.data_ptr(), out.data_ptr(), q16_mode
     torch.cuda.synchronize()
     L.check(DBG.lib().wrs_debug_attn_cross_run(C.byref(a)))
     got = DBG.unpack_activations(out, R, D)
@@ -57,9 +58,10 @@ def test_cross_attention_kernel(gpu, n_audio, G):
     assert err < TOL
 
 
+@pytest.mark.parametrize("q16_mode", [0, 1], ids=["slab_qkv", "fp16_q"])
 @pytest.mark.parametrize("n_rows,G,cache_pos", [(1280, 5, 447), (1280, 5, 112), (1280, 5, 0), (1280, 5, 1), (30, 5, 31), (30, 5, 32),
                                                 (30, 5, 33), (12, 1, 200), (21, 7, 64)])
-def test_self_attention_kernel(gpu, n_rows, G, cache_pos):
+def test_self_attention_kernel(gpu, n_rows, G, cache_pos, q16_mode):
     H, D, n_ctx = 20, 1280, 448
     scale = 64 ** -0.25
     qkv = _randn((n_rows, 3 * D), 11)
@@ -85,12 +87,14 @@ def test_self_attention_kernel(gpu, n_rows, G, cache_pos):
     a = DBG.DebugAttnSelfC()
     a.device_id, a.n_rows, a.rows_per_audio, a.H, a.D, a.n_ctx, a.cache_pos = 0, n_rows, G, H, D, n_ctx, cache_pos
     a.qkv, a.qkv_bias, a.scale = qkv.data_ptr(), bias.data_ptr(), scale
-    a.kc, a.vc, a.anc, a.out_packed = kc.data_ptr(), vc.data_ptr(), anc_d.data_ptr(), out.data_ptr()
+    a.kc, a.vc, a.anc, a.out_packed, a.q16_mode = kc.data_ptr(), vc.data_ptr(), anc_d.data_ptr(), out.data_ptr(), q16_mode
     torch.cuda.synchronize()
     L.check(DBG.lib().wrs_debug_attn_self_run(C.byref(a)))
     got = DBG.unpack_activations(out, n_rows, D)
     x = qkv + bias
     qn = x[:, :D] * scale
+    if q16_mode:
+        qn = qn.to(torch.float16).float()  # the query reaches the kernel as fp16 in this form
     kn = (x[:, D:2 * D] * scale).to(torch.float16)
     vn = x[:, 2 * D:].to(torch.float16)
     # the new token's k/v are appended at cache_pos of the row's own physical row; nothing else is touched.  (The kernel

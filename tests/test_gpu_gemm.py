@@ -300,3 +300,99 @@ def test_decode_step_small_row_paths(gpu, M):
     err = _rel_err(out[:, :V], a.float() @ w.t())
     print(f"dec(small) logits M={M} rel_err={err:.2e}")
     assert err < TOL_F32
+
+
+# ------------------------------------------------------------------------------------------------ persistent ring GEMM
+def _pring(a16, w32, M, N, K, mode, bm, *, bias=None, scale=1.0, scale_n_end=0, x0=None, ldc=None, qkv=None):
+    """one launch of the persistent ring GEMM (csrc/gemm_pring.hip) through wrs_debug_gemm_f16."""
+    dev = _dev()
+    g = DBG.DebugGemmC()
+    g.device_id, g.path, g.M, g.N, g.K = 0, DBG.PATH_PRING, M, N, K
+    rows_pad = -(-M // 128) * 128
+    ap = DBG.pack_activations(a16, rows_pad)
+    g.a, g.a_packed, g.packed_rows = ap.data_ptr(), 1, rows_pad
+    g.w, g.n_w, g.k_w = w32.data_ptr(), N, K
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.scale, g.scale_n_end = scale, scale_n_end
+    g.pring_mode, g.pring_bm = mode, bm
+    keep = []
+    if mode == DBG.PRING_RESID:
+        out = x0.clone()
+        g.ldc = N
+    elif mode == DBG.PRING_GELU_PACKED:
+        out = torch.zeros(rows_pad * N, dtype=torch.float16, device=dev)
+        g.ldc = N
+    elif mode == DBG.PRING_QKV:
+        d, n_ctx, cache_pos, phys_mul = N // 3, qkv["n_ctx"], qkv["cache_pos"], qkv["phys_mul"]
+        out = torch.zeros(M, d, dtype=torch.float16, device=dev)
+        g.ldc = d
+        g.kcache, g.vcache = qkv["kc"].data_ptr(), qkv["vc"].data_ptr()
+        g.n_ctx, g.cache_pos, g.phys_mul = n_ctx, cache_pos, phys_mul
+    else:
+        out = torch.zeros(M, ldc or N, dtype=torch.float16, device=dev)
+        g.ldc = ldc or N
+    g.c = out.data_ptr()
+    _run(g)
+    if mode == DBG.PRING_GELU_PACKED:
+        out = DBG.unpack_activations(out, M, N)
+    return out.float(), g.pring_workgroups
+
+
+@pytest.mark.parametrize("bm", [64, 128])
+@pytest.mark.parametrize("M", [1280, 500, 2560])
+@pytest.mark.parametrize("K", [D, 4 * D], ids=["K1280", "K5120"])
+def test_pring_residual_epilogue(gpu, M, K, bm):
+    """out-projection / MLP-2 of the decode step: x += A W^T + bias in place on the fp32 residual stream (N = D)."""
+    a = _rand((M, K), 71)
+    w = _rand((D, K), 72, K ** -0.5).float()
+    bias = _rand((D,), 73, 0.1).float()
+    x0 = _rand((M, D), 74).float()
+    got, wgs = _pring(a, w, M, D, K, DBG.PRING_RESID, bm, bias=bias, x0=x0)
+    ref = x0 + a.float() @ w.t() + bias
+    err = _rel_err(got, ref)
+    print(f"pring RESID M={M} K={K} bm={bm} workgroups={wgs} rel_err={err:.2e}")
+    assert err < TOL_F32
+
+
+@pytest.mark.parametrize("M", [1280, 500])
+def test_pring_query_and_mlp1_epilogues(gpu, M):
+    a = _rand((M, D), 81)
+    w = _rand((D, D), 82, D ** -0.5).float()
+    bias = _rand((D,), 83, 0.1).float()
+    scale = 64 ** -0.25
+    got, wgs = _pring(a, w, M, D, D, DBG.PRING_F16, 64, bias=bias, scale=scale, scale_n_end=D)
+    err = _rel_err(got, (a.float() @ w.t() + bias) * scale)
+    print(f"pring F16 (cross query) M={M} workgroups={wgs} rel_err={err:.2e}")
+    assert err < TOL_F16
+    w1 = _rand((4 * D, D), 84, D ** -0.5).float()
+    b1 = _rand((4 * D,), 85, 0.1).float()
+    for bm in (128, 64):
+        got, wgs = _pring(a, w1, M, 4 * D, D, DBG.PRING_GELU_PACKED, bm, bias=b1)
+        err = _rel_err(got, _gelu(a.float() @ w1.t() + b1))
+        print(f"pring GELU_PACKED (MLP-1) M={M} bm={bm} workgroups={wgs} rel_err={err:.2e}")
+        assert err < TOL_F16
+
+
+@pytest.mark.parametrize("M,cache_pos", [(1280, 17), (500, 0), (1280, 447)])
+def test_pring_qkv_epilogue_writes_cache(gpu, M, cache_pos):
+    """QKV projection of the decode step: q (bias, scale) -> fp16 [M, D]; k (scale) and v (bias) -> the K/V cache rows at the
+    step's position (Cached::forward, model.rs:83-87); nothing else in the cache is touched."""
+    n_ctx = 448
+    a = _rand((M, D), 91)
+    w = _rand((3 * D, D), 92, D ** -0.5).float()
+    bias = _rand((3 * D,), 93, 0.1).float()
+    bias[D:2 * D] = 0.0  # the key projection has no bias (model.rs:138-141)
+    scale = 64 ** -0.25
+    kc = _rand((M, n_ctx, D), 94, 1.0).to(torch.float16)
+    vc = _rand((M, n_ctx, D), 95, 1.0).to(torch.float16)
+    kc0, vc0 = kc.clone(), vc.clone()
+    got_q, wgs = _pring(a, w, M, 3 * D, D, DBG.PRING_QKV, 128, bias=bias, scale=scale, scale_n_end=2 * D,
+                        qkv=dict(kc=kc, vc=vc, n_ctx=n_ctx, cache_pos=cache_pos, phys_mul=1))
+    ref = a.float() @ w.t() + bias
+    ref[:, :2 * D] *= scale
+    assert _rel_err(got_q, ref[:, :D]) < TOL_F16
+    assert _rel_err(kc[:, cache_pos].float(), ref[:, D:2 * D]) < TOL_F16
+    assert _rel_err(vc[:, cache_pos].float(), ref[:, 2 * D:]) < TOL_F16
+    kc0[:, cache_pos], vc0[:, cache_pos] = kc[:, cache_pos], vc[:, cache_pos]
+    assert torch.equal(kc, kc0) and torch.equal(vc, vc0)
+    print(f"pring QKV M={M} cache_pos={cache_pos} workgroups={wgs}: q/k/v ok")

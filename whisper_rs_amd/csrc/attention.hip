@@ -367,6 +367,9 @@ struct SelfAttnParams {
     const StepParams* sp;
     half_t* out;  // packed activation order
     int rows_per_audio;  // beams of one audio are consecutive rows and share most of their cached history
+    // q16 != null: the new token's q is fp16 [n_rows, D] with bias and scale applied, and its k / v are ALREADY in the cache
+    // at sp->cache_pos (written by the QKV GEMM's epilogue); slab / bias are unused
+    const half_t* q16;
 };
 
 __device__ __forceinline__ void slab_chunk8(const float* __restrict__ slab, int ksplit, int64_t slab_stride, int64_t off,
@@ -410,9 +413,19 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
         return;
     }
 
-    // new token: q, k, v chunk c from the QKV slabs
+    // new token: q, k, v chunk c — from the cache / the fp16 query buffer, or from the QKV slabs
     float qv[8], kn[8], vn[8];
-    {
+    if (p.q16) {
+        const half8 q8 = *reinterpret_cast<const half8*>(p.q16 + (int64_t)row * D + col);
+        const half8 k8 = *reinterpret_cast<const half8*>(p.kc + (int64_t)phys * row_stride + (int64_t)cpos * D + col);
+        const half8 v8 = *reinterpret_cast<const half8*>(p.vc + (int64_t)phys * row_stride + (int64_t)cpos * D + col);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            qv[j] = (float)q8[j];
+            kn[j] = (float)k8[j];
+            vn[j] = (float)v8[j];
+        }
+    } else {
         const int64_t ss = (int64_t)p.m_pad * 3 * D, off = (int64_t)row * 3 * D + col;
         slab_chunk8(p.slab, p.ksplit, ss, off, p.bias, col, qv);
         slab_chunk8(p.slab, p.ksplit, ss, off + D, p.bias, D + col, kn);
@@ -512,10 +525,28 @@ void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float*
                       const StepParams* sp, half_t* out, hipStream_t s) {
     WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && qkv_slab && qkv_bias && ksplit >= 1, "attn_self: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
     WRS_REQUIRE(rows_per_audio >= 1 && n_rows % rows_per_audio == 0, "attn_self: rows %d not a multiple of %d", n_rows, rows_per_audio);
-    SelfAttnParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio};
+    SelfAttnParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio, nullptr};
     const int64_t units = (int64_t)(n_rows / rows_per_audio) * ((H + 3) / 4);
     const unsigned grid = (unsigned)(8 * cdiv(units, 8) * rows_per_audio);
     attn_self_kernel<<<grid, 256, 0, s>>>(p);
+}
+
+void launch_attn_self_q16(const half_t* q16, half_t* kc, half_t* vc, const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows,
+                          int rows_per_audio, int phys_mul, int H, int D, const StepParams* sp, half_t* out, hipStream_t s) {
+    WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && q16, "attn_self: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
+    WRS_REQUIRE(rows_per_audio >= 1 && n_rows % rows_per_audio == 0, "attn_self: rows %d not a multiple of %d", n_rows, rows_per_audio);
+    SelfAttnParams p{nullptr, 1, 0, nullptr, 1.f, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio, q16};
+    const int64_t units = (int64_t)(n_rows / rows_per_audio) * ((H + 3) / 4);
+    const unsigned grid = (unsigned)(8 * cdiv(units, 8) * rows_per_audio);
+    attn_self_kernel<<<grid, 256, 0, s>>>(p);
+}
+
+void launch_attn_cross_q16(const half_t* q16, const half_t* kp, const half_t* vp, int n_audio, int G, int T, int H, half_t* out, hipStream_t s) {
+    WRS_REQUIRE(G >= 1 && G <= 16, "attn_cross: group size %d not in 1..16", G);
+    WRS_REQUIRE(T >= 1 && q16, "attn_cross: bad argument");
+    AttnParams p{q16, (int64_t)H * 64, kp, vp, T, (int)round_up(T, 32), H, G, G, out, 0, nullptr, 0, 0, nullptr, 1.f, 0, 0};
+    dim3 grid(1, (unsigned)H, (unsigned)n_audio);
+    attn_mfma_kernel<true, 1><<<grid, XA_WAVES * 64, 0, s>>>(p);
 }
 
 }  // namespace wrs

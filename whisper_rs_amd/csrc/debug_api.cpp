@@ -79,6 +79,26 @@ int wrs_debug_gemm_f16(wrs_debug_gemm* g) {
             SkinnyEpi e;
             e.kind = SK_F32; e.c = g->c; e.ldc = g->ldc; e.bias = g->bias; e.act = g->act; e.scale = g->scale; e.scale_n_end = g->scale_n_end;
             launch_gemm_skinny(reinterpret_cast<const half_t*>(g->a), wp.as<half_t>(), (int)g->M, g->N, n_pad, g->K, 1, e, s);
+        } else if (g->path == WRS_GEMM_PATH_PRING) {
+            WRS_REQUIRE(g->a_packed && g->c, "wrs_debug_gemm_f16: the persistent ring GEMM takes packed A");
+            PringEpi e;
+            e.mode = g->pring_mode; e.bias = g->bias; e.scale = g->scale; e.scale_n_end = g->scale_n_end; e.ldc = g->ldc;
+            if (g->pring_mode == WRS_PRING_RESID) e.x = reinterpret_cast<float*>(g->c);
+            else e.c16 = reinterpret_cast<half_t*>(g->c);
+            DevBuf sp;
+            if (g->pring_mode == WRS_PRING_QKV) {
+                WRS_REQUIRE(g->kcache && g->vcache && g->n_ctx > 0 && g->cache_pos >= 0 && g->cache_pos < g->n_ctx && g->phys_mul >= 1, "wrs_debug_gemm_f16: bad QKV cache arguments");
+                sp.alloc(sizeof(StepParams));
+                StepParams h{};
+                h.cache_pos = g->cache_pos; h.n_rows = (int)g->M;
+                HIP_CHECK(hipMemcpyAsync(sp.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                e.kcache = reinterpret_cast<half_t*>(g->kcache); e.vcache = reinterpret_cast<half_t*>(g->vcache);
+                e.d_model = (int)(g->N / 3); e.cache_row_stride = (int64_t)g->n_ctx * (g->N / 3); e.phys_mul = g->phys_mul; e.sp = sp.as<StepParams>();
+            }
+            launch_gemm_pring(reinterpret_cast<const half_t*>(g->a), g->packed_rows, wp.as<half_t>(), g->M, g->N, g->K, g->pring_bm, e, s);
+            HIP_CHECK(hipStreamSynchronize(s));
+            g->pring_workgroups = pring_debug_last_wgs();
         } else {
             WRS_THROW(WRS_EUNSUPPORTED, "wrs_debug_gemm_f16: unknown path %d", g->path);
         }
@@ -102,6 +122,33 @@ int wrs_debug_attn_self_run(wrs_debug_attn_self* a) {
         HIP_CHECK(hipMemcpyAsync(sp.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
         anc.alloc((size_t)2 * R * a->n_ctx * 4);
         HIP_CHECK(hipMemcpyAsync(anc.p, a->anc, (size_t)R * a->n_ctx * 4, hipMemcpyDeviceToDevice, s));
+        if (a->q16_mode) {
+            // the >= 480-row form: q as fp16 [R, D] and the new k / v already in the cache (what the QKV GEMM's epilogue leaves);
+            // prepared on the host from the same qkv / bias / scale
+            const int D = a->D;
+            std::vector<float> qkv((size_t)R * 3 * D), bias((size_t)3 * D);
+            HIP_CHECK(hipMemcpy(qkv.data(), a->qkv, qkv.size() * 4, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(bias.data(), a->qkv_bias, bias.size() * 4, hipMemcpyDeviceToHost));
+            std::vector<half_t> q16((size_t)R * D), k16((size_t)D), v16((size_t)D);
+            DevBuf qd;
+            qd.alloc(q16.size() * 2);
+            for (int r = 0; r < R; ++r) {
+                for (int c = 0; c < D; ++c) {
+                    q16[(size_t)r * D + c] = (half_t)((qkv[(size_t)r * 3 * D + c] + bias[c]) * a->scale);
+                    k16[c] = (half_t)((qkv[(size_t)r * 3 * D + D + c] + bias[D + c]) * a->scale);
+                    v16[c] = (half_t)(qkv[(size_t)r * 3 * D + 2 * D + c] + bias[2 * D + c]);
+                }
+                const size_t off = ((size_t)r * a->n_ctx + a->cache_pos) * D * 2;
+                HIP_CHECK(hipMemcpy((char*)a->kc + off, k16.data(), (size_t)D * 2, hipMemcpyHostToDevice));
+                HIP_CHECK(hipMemcpy((char*)a->vc + off, v16.data(), (size_t)D * 2, hipMemcpyHostToDevice));
+            }
+            HIP_CHECK(hipMemcpy(qd.p, q16.data(), q16.size() * 2, hipMemcpyHostToDevice));
+            launch_attn_self_q16(qd.as<half_t>(), reinterpret_cast<half_t*>(a->kc), reinterpret_cast<half_t*>(a->vc), anc.as<int>(),
+                                 (int64_t)R * a->n_ctx, a->n_ctx, R, a->rows_per_audio, 1, a->H, a->D, sp.as<StepParams>(),
+                                 reinterpret_cast<half_t*>(a->out_packed), s);
+            HIP_CHECK(hipStreamSynchronize(s));
+            return;
+        }
         launch_attn_self(a->qkv, 1, R, a->qkv_bias, a->scale, reinterpret_cast<half_t*>(a->kc), reinterpret_cast<half_t*>(a->vc), anc.as<int>(),
                          (int64_t)R * a->n_ctx, a->n_ctx, R, a->rows_per_audio, 1, a->H, a->D, sp.as<StepParams>(),
                          reinterpret_cast<half_t*>(a->out_packed), s);
@@ -126,6 +173,20 @@ int wrs_debug_attn_cross_run(wrs_debug_attn_cross* a) {
         vp2.alloc(vp.bytes);
         launch_pack_kv(reinterpret_cast<const half_t*>(a->v), a->D, 0, 0, a->n_audio, a->T, a->H, kp2.as<half_t>(), vp2.as<half_t>(), s);
         const int R = a->n_audio * a->G;
+        if (a->q16_mode) {  // the >= 480-row form: the query GEMM's fp16 output (bias and scale applied)
+            const int D = a->D;
+            std::vector<float> q((size_t)R * D), qb((size_t)D);
+            HIP_CHECK(hipMemcpy(q.data(), a->q, q.size() * 4, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(qb.data(), a->q_bias, qb.size() * 4, hipMemcpyDeviceToHost));
+            std::vector<half_t> q16(q.size());
+            for (size_t i = 0; i < q.size(); ++i) q16[i] = (half_t)((q[i] + qb[i % D]) * a->q_scale);
+            DevBuf qd;
+            qd.alloc(q16.size() * 2);
+            HIP_CHECK(hipMemcpy(qd.p, q16.data(), q16.size() * 2, hipMemcpyHostToDevice));
+            launch_attn_cross_q16(qd.as<half_t>(), kp.as<half_t>(), vp2.as<half_t>(), a->n_audio, a->G, a->T, a->H, reinterpret_cast<half_t*>(a->out_packed), s);
+            HIP_CHECK(hipStreamSynchronize(s));
+            return;
+        }
         launch_attn_cross(a->q, 1, R, a->q_bias, a->q_scale, kp.as<half_t>(), vp2.as<half_t>(), a->n_audio, a->G, a->T, a->H,
                           reinterpret_cast<half_t*>(a->out_packed), s);
         HIP_CHECK(hipStreamSynchronize(s));

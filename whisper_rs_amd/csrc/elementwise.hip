@@ -127,6 +127,30 @@ void launch_layernorm(const float* x, const float* g, const float* b, int64_t M,
     }
 }
 
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_packed_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                               const float* __restrict__ b, int M, int D, half_t* __restrict__ xn) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    floatx4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < D ? *reinterpret_cast<const floatx4*>(x + (int64_t)row * D + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    ln_row<NV>(v, D, lane, g, b, xn, nullptr, row);  // packed activation order
+}
+void launch_layernorm_packed(const float* x, const float* g, const float* b, int M, int D, half_t* xn, hipStream_t s) {
+    const unsigned grid = (unsigned)cdiv(M, 4);
+    switch (ln_nv(D)) {
+#define WRS_LNP(NV) case NV: layernorm_packed_kernel<NV><<<grid, 256, 0, s>>>(x, g, b, M, D, xn); break;
+        WRS_LNP(1) WRS_LNP(2) WRS_LNP(3) WRS_LNP(4) WRS_LNP(5)
+#undef WRS_LNP
+        default: layernorm_packed_kernel<8><<<grid, 256, 0, s>>>(x, g, b, M, D, xn); break;
+    }
+}
+
 // decode step: x[m] += bias + sum_s slab[s][m] (fixed order => deterministic), then xn = LN(x).
 // Fuses the split-K reduction of the out-projection / MLP-2 GEMM, the residual add
 // (reference model.rs:302-318) and the next LayerNorm into one pass over [M, D].

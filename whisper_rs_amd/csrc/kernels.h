@@ -88,6 +88,29 @@ int gemm_debug_last();
 void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t N, int64_t K, const GemmEpi& epi,
                      hipStream_t s);
 
+// ---------------------------------------------------------------- persistent ring GEMM (decode step, >= 480 rows; gemm_pring.hip)
+enum PringMode { PRING_RESID = 0, PRING_F16 = 1, PRING_GELU_PACKED = 2, PRING_QKV = 3 };
+struct PringEpi {
+    int mode = PRING_RESID;
+    const float* bias = nullptr;   // [N] or null
+    float scale = 1.f;             // applied after the bias to columns n < scale_n_end
+    int scale_n_end = 0;
+    float* x = nullptr;            // RESID: fp32 [M, ldc], x += acc + bias in place (the residual stream)
+    half_t* c16 = nullptr;         // F16: fp16 [M, ldc]; GELU_PACKED: packed-activation order (K' = N); QKV: q fp16 [M, ldc]
+    int64_t ldc = 0;
+    // QKV: N = 3 * d_model; columns [D, 2D) -> kcache, [2D, 3D) -> vcache at [m * phys_mul][sp->cache_pos][.]
+    half_t* kcache = nullptr;
+    half_t* vcache = nullptr;
+    int d_model = 0;
+    int64_t cache_row_stride = 0;  // halfs per physical row (= n_ctx * D)
+    int phys_mul = 1;
+    const StepParams* sp = nullptr;
+};
+// tile rows bm = 64 or 128 (x 128 columns), no split-K; packed_rows >= round_up(M, bm); W packed with n_pad multiple of 128
+void launch_gemm_pring(const half_t* a_packed, int64_t packed_rows, const half_t* w_packed, int64_t M, int64_t N, int64_t K, int bm,
+                       const PringEpi& epi, hipStream_t s);
+int pring_debug_last_wgs();
+
 // ---------------------------------------------------------------- skinny GEMM (decode, M <= 320)
 enum SkinnyKind { SK_F16 = 0, SK_F32 = 1, SK_SLAB = 2, SK_QKV_SELF = 3 };
 struct SkinnyEpi {
@@ -150,6 +173,8 @@ void launch_mel_prep(const float* mel, int64_t n_batch, int64_t n_frames, int64_
 // y = LN(x) * g + b (eps 1e-5); x fp32 [M, D]; out16 and/or out32 may be null
 void launch_layernorm(const float* x, const float* g, const float* b, int64_t M, int D, half_t* out16, float* out32,
                       hipStream_t s);
+// xn = LN(x) in PACKED activation order (decode step: the GEMM epilogues update x in place, this only normalises)
+void launch_layernorm_packed(const float* x, const float* g, const float* b, int M, int D, half_t* xn, hipStream_t s);
 // x[m] += bias + sum_s slab[s][m]; xn = LN(x) in PACKED activation order.  slab [ksplit][m_pad][D]
 void launch_finish_residual_ln(float* x, const float* slab, int ksplit, int m_pad, const float* bias, const float* g,
                                const float* b, int M, int D, half_t* xn, hipStream_t s);
@@ -188,6 +213,12 @@ void launch_attn_cross(const float* q_slab, int q_ksplit, int q_m_pad, const flo
 void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc,
                       const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, int rows_per_audio, int phys_mul, int H, int D,
                       const StepParams* sp, half_t* out, hipStream_t s);
+// same with the new token's q given as fp16 [n_rows, D] (bias and scale applied) and its k / v already appended to the
+// cache at sp->cache_pos by the QKV GEMM's epilogue (PRING_QKV)
+void launch_attn_self_q16(const half_t* q16, half_t* kc, half_t* vc, const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows,
+                          int rows_per_audio, int phys_mul, int H, int D, const StepParams* sp, half_t* out, hipStream_t s);
+// cross-attention with the query projection given as fp16 [n_audio * G, D] (bias and scale applied)
+void launch_attn_cross_q16(const half_t* q16, const half_t* kp, const half_t* vp, int n_audio, int G, int T, int H, half_t* out, hipStream_t s);
 void launch_anc_init(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_phys_rows, int G, hipStream_t s);
 void launch_anc_update(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, const StepParams* sp,
                        const int* src, hipStream_t s);

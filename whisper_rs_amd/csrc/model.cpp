@@ -439,6 +439,7 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.xn.alloc((size_t)st.act_rows * D * 2);
     st.att.alloc((size_t)st.act_rows * D * 2);
     st.h.alloc((size_t)st.act_rows * 4 * D * 2);
+    st.q16.alloc((size_t)st.act_rows * D * 2);
     st.slab.alloc((size_t)40 * m_pad * 4 * D * 4);  // ksplit (<= K/32 <= 40 for N = 4D; <= 160 for N = D) * m_pad * N floats
     st.logits_ld = (int)round_up(V, 8);  // row pitch of the logits buffer (16-byte aligned rows for vector stores)
     st.logits.alloc((size_t)r_cap * st.logits_ld * 4);
@@ -451,6 +452,7 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.n_audio = 0;
     st.pending_src.clear();
     if (const char* e = getenv("WRS_DEC_BIG_GEMM_ROWS")) dec_big_gemm_rows = atoi(e);
+    if (const char* e = getenv("WRS_DEC_SLAB")) dec_slab_path = e[0] == '1';
     if (parity_f32) init_state_f32(st);
 }
 
@@ -530,6 +532,10 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
         }
     };
 
+    if (big && !dec_slab_path) {
+        decoder_step_big(st, rows, phys_mul, q_per_audio, update_anc, want_logits);
+        return;
+    }
     if (update_anc) {
         Timed tm(timer, "dec_anc_update", stream);
         launch_anc_update(st.anc.as<int>(), anc_stride, n_ctx, rows, sp, st.src_d(), stream);
@@ -594,6 +600,88 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
             const float* bb = (l + 1 < L_dec) ? dec[l + 1].attn_ln_b : ln_b;
             launch_finish_residual_ln(st.x.as<float>(), slab, ks_m2, mp, b.mlp2_b, g, bb, rows, D, st.xn.as<half_t>(), stream);
         }
+    }
+    if (want_logits) decoder_logits(st, rows);
+}
+
+// Decode step at >= dec_big_gemm_rows rows: the persistent ring GEMM (gemm_pring.hip) with epilogues that write every
+// consumer's operand directly — no split-K slabs, no "finish" kernels.  Per layer (11 launches):
+//   QKV GEMM (q -> fp16, k / v -> the cache) -> self-attention -> out GEMM (x += ..) -> LN ->
+//   query GEMM (-> fp16) -> cross-attention -> out GEMM (x += ..) -> LN -> MLP-1 GEMM (GELU, packed) -> MLP-2 GEMM (x += ..) -> LN
+void Model::decoder_step_big(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits) {
+    const float scale = std::pow((float)(D / H), -0.25f);
+    const StepParams* sp = st.sp_d();
+    const int64_t anc_stride = (int64_t)st.r_cap * n_ctx;
+    const size_t kv_layer = (size_t)st.r_cap * n_ctx * D;
+    const size_t cross_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
+    const int n_audio = rows / q_per_audio;
+    const double wD = (double)D * D * 2;
+    float* x = st.x.as<float>();
+    half_t* xn = st.xn.as<half_t>();
+    half_t* att = st.att.as<half_t>();
+    half_t* q16 = st.q16.as<half_t>();
+    auto resid = [&](const char* name, const half_t* a, const half_t* w, const float* bias, int64_t K, double bytes) {
+        Timed tm(timer, name, stream, bytes);
+        PringEpi e;
+        e.mode = PRING_RESID; e.bias = bias; e.x = x; e.ldc = D;
+        launch_gemm_pring(a, st.act_rows, w, rows, D, K, 64, e, stream);
+    };
+    auto ln = [&](const float* g, const float* b) {
+        Timed tm(timer, "dec_ln", stream);
+        launch_layernorm_packed(x, g, b, rows, D, xn, stream);
+    };
+    if (update_anc) {
+        Timed tm(timer, "dec_anc_update", stream);
+        launch_anc_update(st.anc.as<int>(), anc_stride, n_ctx, rows, sp, st.src_d(), stream);
+    }
+    {
+        Timed tm(timer, "dec_embed_ln", stream);
+        launch_embed_ln(emb16, dec_pos, sp, st.tokens_d(), dec[0].attn_ln_g, dec[0].attn_ln_b, rows, D, x, xn, stream);
+    }
+    for (int l = 0; l < L_dec; ++l) {
+        const BlockW& b = dec[l];
+        half_t* kc = st.kc.as<half_t>() + l * kv_layer;
+        half_t* vc = st.vc.as<half_t>() + l * kv_layer;
+        {   // x + attn(attn_ln(x))   (model.rs:302-305)
+            Timed tm(timer, "dec_gemm_qkv", stream, 3 * wD);
+            PringEpi e;
+            e.mode = PRING_QKV; e.bias = b.qkv_b; e.scale = scale; e.scale_n_end = 2 * D; e.c16 = q16; e.ldc = D;
+            e.kcache = kc; e.vcache = vc; e.d_model = D; e.cache_row_stride = (int64_t)n_ctx * D; e.phys_mul = phys_mul; e.sp = sp;
+            launch_gemm_pring(xn, st.act_rows, b.qkv_w, rows, 3 * D, D, 128, e, stream);
+        }
+        {
+            Timed tm(timer, "dec_attn_self", stream);
+            launch_attn_self_q16(q16, kc, vc, st.anc.as<int>(), anc_stride, n_ctx, rows, q_per_audio, phys_mul, H, D, sp, att, stream);
+        }
+        resid("dec_gemm_out", att, b.out_w, b.out_b, D, wD);
+        ln(b.cross_ln_g, b.cross_ln_b);
+        {   // + cross_attn(cross_attn_ln(x), xa)   (model.rs:309-310)
+            Timed tm(timer, "dec_gemm_cq", stream, wD);
+            PringEpi e;
+            e.mode = PRING_F16; e.bias = b.cq_b; e.scale = scale; e.scale_n_end = D; e.c16 = q16; e.ldc = D;
+            launch_gemm_pring(xn, st.act_rows, b.cq_w, rows, D, D, 64, e, stream);
+        }
+        {
+            Timed tm(timer, "dec_attn_cross", stream, (double)n_audio * 2.0 * T * D * 2.0);
+            const bool sample = cross_ev_now && (l % cross_ev_stride == 0);
+            const int slot = l / cross_ev_stride;
+            if (sample) {
+                while ((int)cross_ev.size() < 2 * (slot + 1)) { hipEvent_t ev; HIP_CHECK(hipEventCreate(&ev)); cross_ev.push_back(ev); }
+                HIP_CHECK(hipEventRecord(cross_ev[2 * slot], stream));
+            }
+            launch_attn_cross_q16(q16, st.ckp(st.cross_sel) + l * cross_layer, st.cvp(st.cross_sel) + l * cross_layer, n_audio, q_per_audio, T, H, att, stream);
+            if (sample) HIP_CHECK(hipEventRecord(cross_ev[2 * slot + 1], stream));
+        }
+        resid("dec_gemm_out", att, b.cout_w, b.cout_b, D, wD);
+        ln(b.mlp_ln_g, b.mlp_ln_b);
+        {   // + mlp(mlp_ln(x))   (model.rs:315)
+            Timed tm(timer, "dec_gemm_mlp1", stream, 4 * wD);
+            PringEpi e;
+            e.mode = PRING_GELU_PACKED; e.bias = b.mlp0_b; e.c16 = st.h.as<half_t>(); e.ldc = 4 * D;
+            launch_gemm_pring(xn, st.act_rows, b.mlp0_w, rows, 4 * D, D, 128, e, stream);
+        }
+        resid("dec_gemm_mlp2", st.h.as<half_t>(), b.mlp2_w, b.mlp2_b, 4 * (int64_t)D, 4 * wD);
+        ln((l + 1 < L_dec) ? dec[l + 1].attn_ln_g : ln_g, (l + 1 < L_dec) ? dec[l + 1].attn_ln_b : ln_b);
     }
     if (want_logits) decoder_logits(st, rows);
 }

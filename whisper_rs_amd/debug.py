@@ -9,7 +9,8 @@ from . import _lib as L
 
 GEMM_AUTO, GEMM_PP2, GEMM_TILE128, GEMM_TILE128_PACKED, GEMM_RING = 0, 1, 2, 3, 4
 GEMM_NAMES = {0: "auto", 1: "pp2_256x256", 2: "tile128", 3: "tile128_packedA", 4: "ring<4,8>"}
-PATH_TILED, PATH_DEC, PATH_SKINNY_F32, PATH_FUSED_LN = 0, 1, 2, 3
+PATH_TILED, PATH_DEC, PATH_SKINNY_F32, PATH_PRING = 0, 1, 2, 3
+PRING_RESID, PRING_F16, PRING_GELU_PACKED, PRING_QKV = 0, 1, 2, 3
 
 
 class DebugGemmC(C.Structure):
@@ -23,20 +24,21 @@ class DebugGemmC(C.Structure):
                 ("c", C.c_void_p), ("c_f32", C.c_int32), ("c_packed", C.c_int32),
                 ("ldc", C.c_int64), ("c_rows_per_batch", C.c_int64), ("c_batch_rows", C.c_int64), ("c_row_off", C.c_int64),
                 ("ksplit", C.c_int32), ("slab_stride", C.c_int64),
-                ("x_inout", C.c_void_p), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("xn_packed", C.c_void_p)]
+                ("pring_mode", C.c_int32), ("pring_bm", C.c_int32), ("kcache", C.c_void_p), ("vcache", C.c_void_p),
+                ("n_ctx", C.c_int32), ("cache_pos", C.c_int32), ("phys_mul", C.c_int32), ("pring_workgroups", C.c_int32)]
 
 
 class DebugAttnSelfC(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("n_rows", C.c_int32), ("rows_per_audio", C.c_int32), ("H", C.c_int32), ("D", C.c_int32),
                 ("n_ctx", C.c_int32), ("cache_pos", C.c_int32),
                 ("qkv", C.c_void_p), ("qkv_bias", C.c_void_p), ("scale", C.c_float),
-                ("kc", C.c_void_p), ("vc", C.c_void_p), ("anc", C.c_void_p), ("out_packed", C.c_void_p)]
+                ("kc", C.c_void_p), ("vc", C.c_void_p), ("anc", C.c_void_p), ("out_packed", C.c_void_p), ("q16_mode", C.c_int32)]
 
 
 class DebugAttnCrossC(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("n_audio", C.c_int32), ("G", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("T", C.c_int32),
                 ("q", C.c_void_p), ("q_bias", C.c_void_p), ("q_scale", C.c_float),
-                ("k", C.c_void_p), ("v", C.c_void_p), ("out_packed", C.c_void_p)]
+                ("k", C.c_void_p), ("v", C.c_void_p), ("out_packed", C.c_void_p), ("q16_mode", C.c_int32)]
 
 
 P = C.POINTER
