@@ -40,11 +40,15 @@ def _features(n, seed):
     return torch.randn(n, 1500, 1280, generator=g).to(torch.float16).to(torch.float32).numpy()
 
 
-def test_wide_decode_480_rows_teacher_forced(gpu):
+@pytest.mark.parametrize("pring", [False, True], ids=["slab_path", "persistent_ring_path"])
+def test_wide_decode_480_rows_teacher_forced(gpu, monkeypatch, pring):
     """96 audios x beam 5 = 480 decoder rows: the row count at which Model::decoder_step switches to the tiled GEMM path
-    the benchmark runs (model.cpp dec_big_gemm_rows).  Decoder-only (features in), every step against the oracle."""
+    the benchmark runs (model.cpp dec_big_gemm_rows).  Decoder-only (features in), every step against the oracle.
+    Both forms of that path: split-K slabs + finish kernels (default) and the persistent ring GEMM (WRS_DEC_PRING=1)."""
     n = 96
     assert n * 5 >= 480
+    if pring:
+        monkeypatch.setenv("WRS_DEC_PRING", "1")  # read when a decoder state is created
     exact, steps = _teacher_forced_check(gpu, "wide", n, 10, WIDE_MIN_EXACT, feats=_features(n, 7), ids=TokenIds.multilingual(), cand_tol=WIDE_CAND_TOL)
     print(f"wide, {n * 5} rows: {exact}/{steps} selections reproduced exactly")
 

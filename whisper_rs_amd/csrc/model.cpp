@@ -452,7 +452,7 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.n_audio = 0;
     st.pending_src.clear();
     if (const char* e = getenv("WRS_DEC_BIG_GEMM_ROWS")) dec_big_gemm_rows = atoi(e);
-    if (const char* e = getenv("WRS_DEC_SLAB")) dec_slab_path = e[0] == '1';
+    if (const char* e = getenv("WRS_DEC_PRING")) dec_slab_path = e[0] != '1';
     if (parity_f32) init_state_f32(st);
 }
 
@@ -604,8 +604,12 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     if (want_logits) decoder_logits(st, rows);
 }
 
-// Decode step at >= dec_big_gemm_rows rows: the persistent ring GEMM (gemm_pring.hip) with epilogues that write every
-// consumer's operand directly — no split-K slabs, no "finish" kernels.  Per layer (11 launches):
+// Decode step at >= dec_big_gemm_rows rows, alternative form (WRS_DEC_PRING=1): the persistent ring GEMM (gemm_pring.hip)
+// with epilogues that write every consumer's operand directly — no split-K slabs, no "finish" kernels.  Correct (kernel-
+// and model-level parity tests) but NOT faster than the slab path at 1280 rows — measured per layer 12.6 / 11.1 / 31.5 /
+// 34.2 / 34.2 us (out, query, MLP-2, QKV, MLP-1) against 10.1 / 10.1 / 23.9 / 23.4 / 29.7 us for the slab kernels
+// (profiles/r02_gemm_pring_micro.log): a persistent workgroup cannot overlap one tile's epilogue with the next tile's
+// MFMAs, which two co-resident one-tile workgroups do for free — so it is not the default.  Per layer (11 launches):
 //   QKV GEMM (q -> fp16, k / v -> the cache) -> self-attention -> out GEMM (x += ..) -> LN ->
 //   query GEMM (-> fp16) -> cross-attention -> out GEMM (x += ..) -> LN -> MLP-1 GEMM (GELU, packed) -> MLP-2 GEMM (x += ..) -> LN
 void Model::decoder_step_big(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits) {

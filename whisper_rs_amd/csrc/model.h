@@ -141,7 +141,7 @@ struct Model {
     StageTimer* timer = nullptr;            // optional per-kernel timing sink
     int debug_enc_stop = 0;                 // debug: stop the encoder after N launches
     int dec_big_gemm_rows = 480;            // decode steps with at least this many rows use the tiled GEMM (env WRS_DEC_BIG_GEMM_ROWS)
-    bool dec_slab_path = false;             // WRS_DEC_SLAB=1: round-1 form of that path (split-K fp32 slabs + finish kernels), kept for A/B runs
+    bool dec_slab_path = true;              // split-K fp32 slabs + finish kernels; WRS_DEC_PRING=1 selects the persistent-ring form (slower, see model.cpp)
     // live timing of the dominant decode kernel (cross-attention) with HIP events on this stream: every
     // `cross_ev_every`-th decode step is launched eagerly (not from the graph) with event pairs around the
     // kernel in every `cross_ev_stride`-th layer; all other steps replay the captured graph untouched
