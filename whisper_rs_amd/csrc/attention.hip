@@ -15,7 +15,6 @@
 //        kperm(q, j) = j < 4 ? 4q + j : 16 + 4q + (j - 4)
 // (the k-order inside the P·V MFMA is permuted to match the score-register order).
 #include "kernels.h"
-#include <atomic>
 
 namespace wrs {
 
@@ -521,191 +520,12 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
     }
 }
 
-// ------------------------------------------------------------------------------------------ decode self-attention, beam-deduplicated
-// The G beams of an audio share most of their cached history: on the benchmark workload a position is held by ~2.4
-// distinct physical rows, not 5 (profiles/r01_pmc_fetch_write_b256.json: HBM 302 MB per launch against 734 MB of requests).
-// attn_self_kernel above reads every beam's history separately and is bound by the L2->CU traffic of the duplicates.
-// Here ONE wave owns (audio, head) for ALL its beams: per block of 8 positions it fetches each DISTINCT (position, physical
-// row) once — direct-to-LDS loads, exec-masked to the rows the ancestry table references — and every beam then reads its
-// row's K / V chunk from LDS by index.  Same lane layout (8 position groups x 8 chunks of 16 B: every load instruction
-// fetches whole 128-B lines), same single-pass online softmax, per-lane-group running maxima merged at the end.
-// LDS: 4 waves x G x 2 KiB staging + the G ancestry rows.  Replaces Cached::update_cache + the attention of
-// reference model.rs:53-62,159-201 for the decode step.
-template <int G>
-__global__ __launch_bounds__(256) void attn_self_dedup_kernel(const SelfAttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sd_smem[];
-    half8* stage_all = reinterpret_cast<half8*>(sd_smem);                         // [4 waves][G rows][K, V][64 lanes]
-    int* anc_s = reinterpret_cast<int*>(sd_smem + (size_t)4 * G * 2 * 64 * 16);   // [G][n_ctx]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int hpb = (p.H + 3) >> 2;
-    const int a = (int)blockIdx.x / hpb, h = ((int)blockIdx.x % hpb) * 4 + wave;
-    const int g = lane >> 3, c = lane & 7;
-    const int D = p.D;
-    const int cpos = p.sp->cache_pos;  // the new token's slot; cached positions are 0..cpos-1
-    const int row0 = a * G;
-    const int64_t row_stride = (int64_t)p.n_ctx * D;
-    const int* anc = p.anc_base + (int64_t)p.sp->parity * p.anc_buf_stride + (int64_t)row0 * p.n_ctx;
-    for (int i = threadIdx.x; i < G * cpos; i += 256) {
-        const int b = i / cpos, pos = i - b * cpos;
-        anc_s[b * p.n_ctx + pos] = anc[(int64_t)b * p.n_ctx + pos] - row0;  // row index inside the audio, 0..G-1
-    }
-    if (h >= p.H) {  // surplus wave of the last head group: only takes part in the barrier
-        __syncthreads();
-        return;
-    }
-    const int col = h * 64 + c * 8;
-
-    // new token of every beam: q, k, v chunk c (from the QKV slabs, or fp16 q + the cache the QKV GEMM already appended to)
-    float qv[G][8], acc[G][8], m_run[G], l_run[G];
-#pragma unroll
-    for (int b = 0; b < G; ++b) {
-        const int row = row0 + b;
-        float kn[8], vn[8];
-        if (p.q16) {
-            const half8 q8 = *reinterpret_cast<const half8*>(p.q16 + (int64_t)row * D + col);
-            const half8 k8 = *reinterpret_cast<const half8*>(p.kc + (int64_t)row * row_stride + (int64_t)cpos * D + col);
-            const half8 v8 = *reinterpret_cast<const half8*>(p.vc + (int64_t)row * row_stride + (int64_t)cpos * D + col);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { qv[b][j] = (float)q8[j]; kn[j] = (float)k8[j]; vn[j] = (float)v8[j]; }
-        } else {
-            const int64_t ss = (int64_t)p.m_pad * 3 * D, off = (int64_t)row * 3 * D + col;
-            slab_chunk8(p.slab, p.ksplit, ss, off, p.bias, col, qv[b]);
-            slab_chunk8(p.slab, p.ksplit, ss, off + D, p.bias, D + col, kn);
-            slab_chunk8(p.slab, p.ksplit, ss, off + 2 * D, p.bias, 2 * D + col, vn);
-            half8 k16, v16;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                qv[b][j] *= p.scale;
-                k16[j] = (_Float16)(kn[j] * p.scale);
-                v16[j] = (_Float16)vn[j];
-                kn[j] = (float)k16[j];  // use exactly what later steps will read back from the fp16 cache
-                vn[j] = (float)v16[j];
-            }
-            if (g == 0) {
-                *reinterpret_cast<half8*>(p.kc + (int64_t)row * row_stride + (int64_t)cpos * D + col) = k16;
-                *reinterpret_cast<half8*>(p.vc + (int64_t)row * row_stride + (int64_t)cpos * D + col) = v16;
-            }
-        }
-        float s_new = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s_new += qv[b][j] * kn[j];
-        s_new += __shfl_xor(s_new, 1);
-        s_new += __shfl_xor(s_new, 2);
-        s_new += __shfl_xor(s_new, 4);
-        m_run[b] = s_new;  // the new position seeds the running max (weight exp(0) = 1), counted once by group 0
-        l_run[b] = (g == 0) ? 1.f : 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[b][j] = (g == 0) ? vn[j] : 0.f;
-    }
-    __syncthreads();  // anc_s ready
-
-    half8* stage = stage_all + (size_t)wave * G * 2 * 64;
-    for (int p0 = 0; p0 < cpos; p0 += 8) {
-        const int pos = p0 + g;
-        const bool live = pos < cpos;
-        int rb[G];
-        unsigned need = 0;
-#pragma unroll
-        for (int b = 0; b < G; ++b) {
-            rb[b] = live ? min(max(anc_s[b * p.n_ctx + pos], 0), G - 1) : 0;  // (an ancestry entry always names a row of the same audio)
-            if (live) need |= 1u << rb[b];
-        }
-        // each distinct (position, row) once: lanes of a position group whose beams do not reference row r stay masked
-#pragma unroll
-        for (int r = 0; r < G; ++r) {
-            if ((need >> r) & 1u) {
-                const int64_t off = (int64_t)(row0 + r) * row_stride + (int64_t)pos * D + col;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.kc + off),
-                                                 (__attribute__((address_space(3))) void*)(stage + (r * 2 + 0) * 64), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.vc + off),
-                                                 (__attribute__((address_space(3))) void*)(stage + (r * 2 + 1) * 64), 16, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int b = 0; b < G; ++b) {
-            const half8 k8 = stage[(rb[b] * 2 + 0) * 64 + lane];
-            const half8 v8 = stage[(rb[b] * 2 + 1) * 64 + lane];
-            float x = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x += qv[b][j] * (float)k8[j];
-            x += __shfl_xor(x, 1);
-            x += __shfl_xor(x, 2);
-            x += __shfl_xor(x, 4);
-            const float sc = live ? x : -INFINITY;
-            const float m_new = fmaxf(m_run[b], sc);
-            const float alpha = __expf(m_run[b] - m_new);
-            const float w = __expf(sc - m_new);  // exp(-inf) = 0 for padded slots
-            l_run[b] = l_run[b] * alpha + w;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[b][j] = acc[b][j] * alpha + w * (float)v8[j];
-            m_run[b] = m_new;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area is overwritten by the next block's loads
-    }
-    // merge the 8 position groups (lanes differing in bits 3..5), each with its own running max
-#pragma unroll
-    for (int b = 0; b < G; ++b) {
-        float mm = m_run[b];
-#pragma unroll
-        for (int o = 8; o < 64; o <<= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
-        const float f = __expf(m_run[b] - mm);
-        float l = l_run[b] * f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[b][j] *= f;
-#pragma unroll
-        for (int o = 8; o < 64; o <<= 1) {
-            l += __shfl_xor(l, o);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[b][j] += __shfl_xor(acc[b][j], o);
-        }
-        if (g == 0) {
-            const float inv = 1.f / l;
-            half8 r;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = (_Float16)(acc[b][j] * inv);
-            *reinterpret_cast<half8*>(p.out + pa_off(row0 + b, col, D >> 5)) = r;  // packed activation order
-        }
-    }
-}
-
-template <int G>
-static void launch_attn_self_dedup(const SelfAttnParams& p, hipStream_t s) {
-    const size_t lds = (size_t)4 * G * 2 * 64 * 16 + (size_t)G * p.n_ctx * 4;
-    static std::atomic<bool> attr[64];
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr[dev].load(std::memory_order_acquire)) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_self_dedup_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 4096));
-        attr[dev].store(true, std::memory_order_release);
-    }
-    const unsigned grid = (unsigned)((p.n_rows / G) * ((p.H + 3) / 4));
-    attn_self_dedup_kernel<G><<<grid, 256, lds, s>>>(p);
-}
-
-// rows_per_audio beams, phys_mul == 1: the deduplicating kernel; otherwise (one row per audio: greedy, prompt prefill rows) false
-static bool attn_self_try_dedup(const SelfAttnParams& p, hipStream_t s) {
-    static const bool off = getenv("WRS_SELF_DEDUP") && getenv("WRS_SELF_DEDUP")[0] == '0';
-    if (off || p.phys_mul != 1) return false;
-    switch (p.rows_per_audio) {
-        case 2: launch_attn_self_dedup<2>(p, s); return true;
-        case 3: launch_attn_self_dedup<3>(p, s); return true;
-        case 4: launch_attn_self_dedup<4>(p, s); return true;
-        case 5: launch_attn_self_dedup<5>(p, s); return true;
-        case 6: launch_attn_self_dedup<6>(p, s); return true;
-        case 7: launch_attn_self_dedup<7>(p, s); return true;
-        case 8: launch_attn_self_dedup<8>(p, s); return true;
-        default: return false;
-    }
-}
-
 void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc,
                       const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, int rows_per_audio, int phys_mul, int H, int D,
                       const StepParams* sp, half_t* out, hipStream_t s) {
     WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && qkv_slab && qkv_bias && ksplit >= 1, "attn_self: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
     WRS_REQUIRE(rows_per_audio >= 1 && n_rows % rows_per_audio == 0, "attn_self: rows %d not a multiple of %d", n_rows, rows_per_audio);
     SelfAttnParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio, nullptr};
-    if (attn_self_try_dedup(p, s)) return;
     const int64_t units = (int64_t)(n_rows / rows_per_audio) * ((H + 3) / 4);
     const unsigned grid = (unsigned)(8 * cdiv(units, 8) * rows_per_audio);
     attn_self_kernel<<<grid, 256, 0, s>>>(p);
@@ -716,7 +536,6 @@ void launch_attn_self_q16(const half_t* q16, half_t* kc, half_t* vc, const int* 
     WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && q16, "attn_self: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
     WRS_REQUIRE(rows_per_audio >= 1 && n_rows % rows_per_audio == 0, "attn_self: rows %d not a multiple of %d", n_rows, rows_per_audio);
     SelfAttnParams p{nullptr, 1, 0, nullptr, 1.f, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio, q16};
-    if (attn_self_try_dedup(p, s)) return;
     const int64_t units = (int64_t)(n_rows / rows_per_audio) * ((H + 3) / 4);
     const unsigned grid = (unsigned)(8 * cdiv(units, 8) * rows_per_audio);
     attn_self_kernel<<<grid, 256, 0, s>>>(p);
