@@ -303,6 +303,11 @@ int wrs_window_pool_create(wrs_model* const* models, int32_t n_models, const wrs
 /* attach a tokenizer to every worker (outputs then carry `text`); non-owning, NULL detaches */
 int wrs_window_pool_set_tokenizer(wrs_window_pool* p, const wrs_tokenizer* tok);
 int wrs_window_pool_run_audio(wrs_window_pool* p, const float* audio, int64_t n_windows, int mem_kind, wrs_decode_result* result);
+/* ONE long recording with the reference's whole-file normalisation: mel = wrs_log_mel_spectrogram of the whole file
+ * ([80, n_frames] f32 host: global max, transcribe.rs:111-112), cut at the fixed 3000-frame stride (the reference's
+ * `seek += N_FRAMES` branch, transcribe.rs:231; the last window zero-padded, audio.rs:213-228); result->outputs[w] is window
+ * w.  Same tokens as wrs_transcribe_task_run_chunked on that recording, sharded over the pool's replicas. */
+int wrs_window_pool_run_mel(wrs_window_pool* p, const float* mel, int64_t n_frames, wrs_decode_result* result);
 void wrs_window_pool_destroy(wrs_window_pool* p);
 
 /* ---------------------------------------------------------------- transcribe (src/transcribe.rs) */

@@ -80,3 +80,28 @@ def test_text_outputs_with_tokenizer(gpu):
     out = task.run(mel_windows(1))[0]
     assert out.text == tok.decode(out.tokens)
     task.close()
+
+
+def test_window_pool_on_whole_file_spectrogram_equals_chunked_transcribe(gpu):
+    """one long recording, the reference's whole-file log-mel normalisation (transcribe.rs:111-112), fixed-stride windows
+    sharded over a pool's replicas (wrs_window_pool_run_mel) == TranscribeTask::run_chunked on the same recording."""
+    import helpers
+    from whisper_rs_amd.consts import MODEL_DIMS
+    audio = synth.make_audio(1, seed=5, n_samples=16000 * 95)[0]
+    audio[16000 * 40:16000 * 70] *= 0.01  # a quiet stretch: per-window and whole-file normalisation now differ
+    dopt = gpu.DecodeOptions(sample_len=8, max_audio=2)
+    gt = gpu.TranscribeTask(gpu_model(gpu, "nano"), gpu.TranscribeOptions(decode=dopt, prompt=gpu.TranscribePrompt.None_(False)))
+    want = gt.run_chunked(audio, 2)
+    gt.close()
+    mel = gpu.audio.log_mel_spectrogram(audio)  # [80, 9500], global max
+    replicas = [gpu.Whisper(MODEL_DIMS["nano"], helpers.weights("nano")) for _ in range(2)]
+    pool = gpu.WindowPool(replicas, TokenIds.english(), dopt)
+    outs = pool.run_mel(mel)
+    assert len(outs) == 4 == len(want.windows)
+    np.testing.assert_array_equal(np.concatenate([o.tokens for o in outs]), want.tokens)
+    # the per-window entry normalises each window as its own recording: on this file that is a different spectrogram
+    per_window = pool.run_audio(np.stack([np.pad(audio[i * 480000:(i + 1) * 480000], (0, max(0, 480000 - len(audio[i * 480000:(i + 1) * 480000])))) for i in range(4)]))
+    assert len(per_window) == 4
+    pool.close()
+    for r in replicas:
+        r.close()

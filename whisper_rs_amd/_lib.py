@@ -124,6 +124,7 @@ SYMBOLS = {
     "wrs_window_pool_create": (C.c_int, [P(C.c_void_p), C.c_int32, P(TokenIdsC), P(DecodeOptionsC), C.c_int, P(C.c_void_p)]),
     "wrs_window_pool_set_tokenizer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wrs_window_pool_run_audio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, P(DecodeResultC)]),
+    "wrs_window_pool_run_mel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, P(DecodeResultC)]),
     "wrs_window_pool_destroy": (None, [C.c_void_p]),
     "wrs_transcribe_task_create": (C.c_int, [C.c_void_p, P(TokenIdsC), P(TranscribeOptionsC), P(C.c_void_p)]),
     "wrs_transcribe_task_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, P(TranscribeOutputC)]),

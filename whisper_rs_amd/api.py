@@ -540,6 +540,18 @@ class WindowPool:
             a = _f32(audio_)
             assert a.ndim == 2 and a.shape[1] == N_SAMPLES
             L.check(self._lib.wrs_window_pool_run_audio(self._h, _ptr(a), a.shape[0], L.WRS_MEM_HOST, C.byref(res)))
+        return self._collect(res)
+
+    def run_mel(self, mel: np.ndarray) -> List[DecodeOutput]:
+        """one long recording's log-mel spectrogram [80, n_frames] (whole-file normalisation, as the reference): fixed-stride
+        3000-frame windows dealt to the pool's workers; outputs in window order."""
+        mel = _f32(mel)
+        assert mel.ndim == 2 and mel.shape[0] == N_MELS
+        res = L.DecodeResultC()
+        L.check(self._lib.wrs_window_pool_run_mel(self._h, _ptr(mel), mel.shape[1], C.byref(res)))
+        return self._collect(res)
+
+    def _collect(self, res):
         self.n_steps = res.n_steps
         outs = []
         for i in range(res.n_outputs):

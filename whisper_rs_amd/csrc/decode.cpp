@@ -38,7 +38,7 @@ bool DecodeTask::side_idle() {
 // Queue log-mel, AudioEncoder and the cross-attention K/V projection of a window batch on the side stream, into the
 // cross-K/V buffer the decode steps are not reading.  The MFMA-bound encoder of batch i+1 then overlaps the HBM-bound
 // decode steps of batch i.  The encoder workspace is single: queued batches run one after the other on the side stream.
-void DecodeTask::encode_async(const float* audio, int n_audio, int mem_kind) {
+void DecodeTask::encode_async(const float* audio, int n_audio, int mem_kind, bool is_mel) {
     WRS_REQUIRE(audio && n_audio >= 1 && n_audio <= max_audio, "encode_async: %d windows exceed the task capacity %d", n_audio, max_audio);
     WRS_REQUIRE(pending.size() < 2, "encode_async: two batches are already queued (call run_pending first)");
     WRS_REQUIRE(!m->parity_f32, "encode_async: the f32 parity mode has no overlapped path");
@@ -60,15 +60,19 @@ void DecodeTask::encode_async(const float* audio, int n_audio, int mem_kind) {
     hipStream_t main_stream = m->stream;
     m->stream = side;  // every launch helper of the model enqueues on m->stream
     try {
-        const float* a_d = audio;
-        if (mem_kind == WRS_MEM_HOST) {
-            audio_dev.ensure((size_t)n_audio * WRS_N_SAMPLES * 4);
-            HIP_CHECK(hipMemcpyAsync(audio_dev.p, audio, (size_t)n_audio * WRS_N_SAMPLES * 4, hipMemcpyHostToDevice, side));
-            a_d = audio_dev.as<float>();
+        if (is_mel) {  // windows of a spectrogram the caller normalised itself (whole-file max): [n_audio, 80, 3000]
+            m->load_mel(audio, n_audio, mem_kind, WRS_N_FRAMES, 0);
+        } else {
+            const float* a_d = audio;
+            if (mem_kind == WRS_MEM_HOST) {
+                audio_dev.ensure((size_t)n_audio * WRS_N_SAMPLES * 4);
+                HIP_CHECK(hipMemcpyAsync(audio_dev.p, audio, (size_t)n_audio * WRS_N_SAMPLES * 4, hipMemcpyHostToDevice, side));
+                a_d = audio_dev.as<float>();
+            }
+            mel_dev.ensure((size_t)n_audio * 80 * WRS_N_FRAMES * 4);
+            log_mel_device(mel_ws, a_d, n_audio, WRS_N_SAMPLES, nullptr, mel_dev.as<float>(), side);
+            m->load_mel(mel_dev.as<float>(), n_audio, WRS_MEM_DEVICE, WRS_N_FRAMES, 0);
         }
-        mel_dev.ensure((size_t)n_audio * 80 * WRS_N_FRAMES * 4);
-        log_mel_device(mel_ws, a_d, n_audio, WRS_N_SAMPLES, nullptr, mel_dev.as<float>(), side);
-        m->load_mel(mel_dev.as<float>(), n_audio, WRS_MEM_DEVICE, WRS_N_FRAMES, 0);
         m->encoder_from_mel_t(n_audio);
         st.cross_wsel = buf;
         m->load_cross_kv(st, m->enc_ws.xa16.as<half_t>(), n_audio);

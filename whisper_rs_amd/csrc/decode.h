@@ -94,7 +94,7 @@ struct DecodeTask {
     void run_decode(int n_audio, wrs_decode_result* out);
     // overlapped mode (beyond the reference, whose loop is sequential): queue mel/encoder/cross-K/V of a batch of raw
     // audio windows on the side stream and return; run_pending decodes the oldest queued batch on the main stream
-    void encode_async(const float* audio, int n_audio, int mem_kind);
+    void encode_async(const float* audio, int n_audio, int mem_kind, bool is_mel = false);  // is_mel: [n_audio, 80, 3000] log-mel windows instead of raw audio
     void run_pending(wrs_decode_result* out);
     // test hook: follow externally given beam decisions (tokens/sources per step) and return the device's raw
     // per-step top-k candidates; the window batch must already be in m->enc_ws.mel_t

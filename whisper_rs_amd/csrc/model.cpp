@@ -74,6 +74,15 @@ void Model::collect_cross_events(int n_audio) {
 
 void Model::use() const { HIP_CHECK(hipSetDevice(device)); }
 
+// every launch of a model's work must come from a thread whose current HIP device is the model's (a window pool drives
+// several GPUs from several threads; a kernel launched while another device is current would run on the wrong GPU, on
+// pointers that do not exist there)
+void Model::check_device(const char* what) const {
+    int cur = -1;
+    HIP_CHECK(hipGetDevice(&cur));
+    if (cur != device) WRS_THROW(WRS_ESTATE, "%s: the calling thread's HIP device is %d but the model lives on device %d", what, cur, device);
+}
+
 bool expected_shape(const Model& m, const std::string& name, std::vector<int64_t>& shape) {
     const int64_t D = m.dims.n_audio_states, Dt = m.dims.n_text_states;
     auto ends = [&](const char* suf) {
@@ -331,6 +340,7 @@ void Model::load_mel_window(const float* mel_dev, int64_t n_frames, int64_t seek
 
 void Model::encoder_from_mel_t(int n) {
     WRS_REQUIRE(finalized, "model not finalized");
+    check_device("encoder");
     if (parity_f32) { encoder_f32(n); return; }
     WRS_REQUIRE(n >= 1 && n <= enc_ws.cap, "encoder: bad window count %d", n);
     EncoderWorkspace& w = enc_ws;
@@ -458,6 +468,7 @@ void Model::init_state(DecState& st, int a_cap, int group) {
 
 void Model::load_cross_kv(DecState& st, const half_t* xa16, int n_audio) {
     WRS_REQUIRE(n_audio >= 1 && n_audio <= st.a_cap, "cross K/V: %d audios exceed capacity %d", n_audio, st.a_cap);
+    check_device("cross K/V projection");
     if (parity_f32) { load_cross_kv_f32(st, n_audio); return; }  // from enc_ws.xa32, which always accompanies xa16
     const int64_t M = (int64_t)n_audio * T;
     const float scale = std::pow((float)(D / H), -0.25f);
@@ -494,6 +505,7 @@ static int pick_ksplit(int64_t N, int64_t K, int cap) {
 
 void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits) {
     WRS_REQUIRE(rows >= 1 && rows <= st.r_cap, "decoder_step: bad row count %d", rows);
+    check_device("decoder step");
     WRS_REQUIRE((rows - 1) * phys_mul < st.r_cap, "decoder_step: physical row out of range");
     WRS_REQUIRE(rows % q_per_audio == 0 && rows / q_per_audio <= st.n_audio, "decoder_step: rows %d do not match %d audios x %d", rows, st.n_audio, q_per_audio);
     if (parity_f32) { decoder_step_f32(st, rows, phys_mul, q_per_audio, update_anc, want_logits); return; }
@@ -713,6 +725,7 @@ void Model::decoder_logits(DecState& st, int rows) {
 // token on large-v2, which doubled the latency of every window after the first with condition_on_prev_text.)
 void Model::decoder_prefill(DecState& st, int n_audio, int S, int pos0, int phys_mul, const int* tokens_host, bool all_logits) {
     WRS_REQUIRE(finalized && !parity_f32, "decoder_prefill: not available in this mode");
+    check_device("decoder prefill");
     WRS_REQUIRE(n_audio >= 1 && n_audio <= st.n_audio && S >= 1 && pos0 >= 0 && pos0 + S <= n_ctx, "decoder_prefill: bad shape (%d audios, %d tokens at %d)", n_audio, S, pos0);
     WRS_REQUIRE((int64_t)(n_audio - 1) * phys_mul < st.r_cap, "decoder_prefill: physical row out of range");
     WRS_REQUIRE(pos0 == 0, "decoder_prefill: a non-empty cache is not supported (causal attention over cached + new positions)");

@@ -160,6 +160,7 @@ struct Model {
     void set_tensor(const std::string& name, int dtype, const int64_t* shape, int ndim, const void* data, int mem_kind);
     void finalize();
     void use() const;  // hipSetDevice
+    void check_device(const char* what) const;  // throws unless the calling thread's current device is this model's
 
     // encoder over `n` windows; input already in enc_ws.mel_t ([n,3002,80] fp16). Output enc_ws.xa16 / xa32.
     void ensure_encoder_ws(int n);

@@ -16,8 +16,12 @@ struct WindowPool {
     int batch = 1;
     bool overlapped = true;
 
-    void run_audio(const float* audio, int64_t n_windows, int mem_kind, wrs_decode_result* result) {
-        WRS_REQUIRE(audio && result && n_windows >= 1, "window pool: bad argument");
+    // mel != null: windows of ONE recording's spectrogram [80, n_frames] (host), normalised over the whole file as the
+    // reference does (transcribe.rs:111-112); window w = frames w*3000 .. (pad_or_trim, audio.rs:213-228)
+    void run_audio(const float* audio, int64_t n_windows, int mem_kind, wrs_decode_result* result, const float* mel = nullptr,
+                   int64_t n_frames = 0) {
+        const bool is_mel = mel != nullptr;
+        WRS_REQUIRE((audio || is_mel) && result && n_windows >= 1, "window pool: bad argument");
         if (mem_kind == WRS_MEM_DEVICE)
             for (auto& t : tasks) WRS_REQUIRE(t->m->device == tasks[0]->m->device, "window pool: a device buffer can only feed replicas on its own GPU");
         memset(result, 0, sizeof(*result));
@@ -32,10 +36,23 @@ struct WindowPool {
         auto worker = [&](DecodeTask* t) {
             try {
                 t->m->use();
+                std::vector<float> mel_batch[2];  // host staging of spectrogram windows (two batches may be queued)
+                int mel_slot = 0;
                 auto span = [&](int64_t b, const float*& p, int& n) {
-                    p = audio + b * batch * (int64_t)WRS_N_SAMPLES;
                     n = (int)std::min<int64_t>(batch, n_windows - b * batch);
+                    if (!is_mel) { p = audio + b * batch * (int64_t)WRS_N_SAMPLES; return; }
+                    std::vector<float>& buf = mel_batch[mel_slot];
+                    mel_slot ^= 1;
+                    buf.assign((size_t)n * 80 * WRS_N_FRAMES, 0.f);  // 0.0 in log-mel space past the end (audio.rs:226)
+                    for (int i = 0; i < n; ++i) {
+                        const int64_t f0 = (b * batch + i) * (int64_t)WRS_N_FRAMES;
+                        const int64_t nf = std::min<int64_t>(WRS_N_FRAMES, n_frames - f0);
+                        for (int c = 0; c < 80 && nf > 0; ++c)
+                            memcpy(buf.data() + ((size_t)i * 80 + c) * WRS_N_FRAMES, mel + (size_t)c * n_frames + f0, (size_t)nf * 4);
+                    }
+                    p = buf.data();
                 };
+                const int kind = is_mel ? WRS_MEM_HOST : mem_kind;
                 int64_t cur = next.fetch_add(1);
                 if (cur >= n_batches) return;
                 const float* p; int n;
@@ -49,7 +66,7 @@ struct WindowPool {
                 if (!overlapped) {  // one cross-K/V buffer per worker: encoder and decode of a batch back to back
                     for (; cur < n_batches; cur = next.fetch_add(1)) {
                         span(cur, p, n);
-                        t->encode_async(p, n, mem_kind);
+                        t->encode_async(p, n, kind, is_mel);
                         wrs_decode_result r;
                         t->run_pending(&r);
                         deliver(cur, r);
@@ -57,12 +74,12 @@ struct WindowPool {
                     return;
                 }
                 span(cur, p, n);
-                t->encode_async(p, n, mem_kind);
+                t->encode_async(p, n, kind, is_mel);
                 while (cur < n_batches) {
                     const int64_t nxt = next.fetch_add(1);
                     if (nxt < n_batches) {
                         span(nxt, p, n);
-                        t->encode_async(p, n, mem_kind);
+                        t->encode_async(p, n, kind, is_mel);
                     }
                     wrs_decode_result r;
                     t->run_pending(&r);
@@ -128,6 +145,12 @@ int wrs_window_pool_create(wrs_model* const* models, int32_t n_models, const wrs
 }
 int wrs_window_pool_run_audio(wrs_window_pool* p, const float* audio, int64_t n_windows, int mem_kind, wrs_decode_result* result) {
     return guarded([&] { WRS_REQUIRE(p, "null pool"); p->p.run_audio(audio, n_windows, mem_kind, result); });
+}
+int wrs_window_pool_run_mel(wrs_window_pool* p, const float* mel, int64_t n_frames, wrs_decode_result* result) {
+    return guarded([&] {
+        WRS_REQUIRE(p && mel && n_frames >= 1, "wrs_window_pool_run_mel: bad argument");
+        p->p.run_audio(nullptr, cdiv(n_frames, WRS_N_FRAMES), WRS_MEM_HOST, result, mel, n_frames);
+    });
 }
 int wrs_window_pool_set_tokenizer(wrs_window_pool* p, const wrs_tokenizer* tok) {
     return guarded([&] {
