@@ -29,7 +29,12 @@ from oracle import decode as OD
 
 CAND_ERR = 1e-2      # per-candidate log-prob error bound (fp16 path vs fp32 oracle), asserted on every candidate of every step;
                      # measured worst: 6.1e-3 at D <= 768, 9.3e-3 at D = 1280 (logit scale 8.5); f32 parity mode: 6e-6
-DRIFT_TOL = 2e-2     # cumulative-score difference allowed between re-synchronisations
+DRIFT_TOL = 2e-2     # cumulative-score difference allowed over the first 16 free-running steps after a (re-)synchronisation;
+                     # grows with sqrt(steps / 16) beyond (a random walk of per-step errors <= CAND_ERR): drift_tol()
+
+
+def drift_tol(steps_since_sync):
+    return DRIFT_TOL * max(1.0, (steps_since_sync / 16.0) ** 0.5)
 MAX_RESYNC = 12
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LOG = os.path.join(ROOT, "gpurun_out", "parity_splits.jsonl")
@@ -110,7 +115,7 @@ def check_candidates(glp_s, gid_s, olp_full, step, tol=CAND_ERR):
     return worst
 
 
-def explain_split(case, step, G, o_slp_before, g_slp_before, olp_full, o_tok, o_src, g_tok, g_src, eot, bound=2 * CAND_ERR):
+def explain_split(case, step, G, o_slp_before, g_slp_before, olp_full, o_tok, o_src, g_tok, g_src, eot, bound=2 * CAND_ERR, since_sync=16):
     bound = max(bound, 2e-3)  # floor: a run whose few candidates happen to be accurate still has fp16 noise of this order
     """o_* / g_*: the selections [rows] of oracle and device at `step`; *_slp_before: cumulative scores going into the step.
     Returns the records of the audios whose selections differ; asserts each is a near-tie in the ORACLE's own scores."""
@@ -131,13 +136,13 @@ def explain_split(case, step, G, o_slp_before, g_slp_before, olp_full, o_tok, o_
         log_split(rec)
         recs.append(rec)
         assert np.isfinite(margin), f"{case}: step {step} audio {a}: the device selected a candidate the oracle's filters forbid: {rec}"
-        assert drift < DRIFT_TOL, f"{case}: step {step} audio {a}: cumulative scores drifted by {drift:.2e}"
+        assert drift < drift_tol(since_sync), f"{case}: step {step} audio {a}: cumulative scores drifted by {drift:.2e}"
         assert margin <= bound + 2 * drift, (f"{case}: REAL divergence at step {step}, audio {a}: the oracle separates the two selections by "
                                              f"{margin:.2e} > {bound + 2 * drift:.2e} (fp16 noise): {rec}")
     return recs
 
 
-def compare_outputs(gouts, oouts, lp_tol=DRIFT_TOL):
+def compare_outputs(gouts, oouts, lp_tol=4 * DRIFT_TOL):
     for i, (g, o) in enumerate(zip(gouts, oouts)):
         np.testing.assert_array_equal(g.tokens, o.tokens.numpy(), err_msg=f"audio {i}: final token ids differ")
         assert abs(g.sum_logprob - o.sum_logprob) < lp_tol, (i, g.sum_logprob, o.sum_logprob)
@@ -165,7 +170,7 @@ def run_with_resync(case, task, mel, view, G, eot, exact=False, cand_tol=CAND_ER
                 split = s
                 break
             d = float(np.abs(gl[s] - ol[s]).max())
-            assert d < DRIFT_TOL, f"{case}: step {s}: cumulative scores differ by {d:.2e}"
+            assert d < drift_tol(s - forced + 1), f"{case}: step {s}: cumulative scores differ by {d:.2e} ({s - forced + 1} steps after the last synchronisation)"
         if split is None:
             assert gt.shape[0] == n_o, f"{case}: step counts differ: device {gt.shape[0]} vs oracle {n_o}"
             compare_outputs(gouts, oouts)
@@ -177,7 +182,7 @@ def run_with_resync(case, task, mel, view, G, eot, exact=False, cand_tol=CAND_ER
         o_before = ol[split - 1] if split > 0 else np.zeros(R, np.float32)
         g_before = gl[split - 1] if split > 0 else np.zeros(R, np.float32)
         splits += explain_split(case, split, G, o_before, g_before, view.olp(split), ot[split], os_[split], gt[split], gs[split], eot,
-                                bound=2 * worst)
+                                bound=2 * worst, since_sync=split - forced + 1)
         forced = split + 1
     raise AssertionError(f"{case}: more than {MAX_RESYNC} near-tie splits: {splits}")
 

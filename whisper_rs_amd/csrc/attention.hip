@@ -326,6 +326,140 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------ encoder attention, K/V shared through LDS
+// attn_mfma_kernel<false> above lets every wave stream the whole packed K/V of its (batch, head) from L2 by itself: with
+// T = 1500 keys that is 385 KB per wave, 47 waves per (batch, head), 92 GB of L2->CU traffic per encoder layer at 256
+// windows — the kernel ran at 420 TFLOP/s (17 % of the MFMA peak) bound by that traffic, not by its arithmetic.  Here the 8
+// waves of a workgroup (256 queries of one (batch, head)) share every 32-key block: each wave fetches ONE of the block's 8
+// fragments (4 K + 4 V, 1 KiB each, already in MFMA operand order) with a direct-to-LDS load into a 3-slot ring, one
+// barrier per key block, and all 8 waves read the fragments back with lane-linear ds_read_b128.  L2->CU traffic drops 8x;
+// the running-max rescale of the output accumulators is skipped while the maximum does not move (wave-uniform test).
+// Same arithmetic as above (S^T = K Q^T on MFMA, score registers reused as the P.V operand, online softmax in fp32).
+// Also serves the decoder's prompt prefill: causal self-attention (Tq == T) and cross-attention (Tq = prompt length).
+template <int NQ>
+__global__ __launch_bounds__(512) void attn_enc_kernel(const AttnParams p) {
+    __shared__ half8 ring[3][8][64];  // [slot][K fragments 0..3 | V fragments 4..7][lane]: 24 KiB
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // 1-D grid, XCD-aware: all query blocks of one (batch, head) run on ONE XCD so its packed K/V (384 KiB) is fetched into one L2 once
+    const int wq = (p.q_rows_per_batch + 128 * NQ - 1) / (128 * NQ);  // query blocks (8 waves x 16 NQ queries) per (batch, head)
+    const int j = (int)(blockIdx.x >> 3);
+    const int unit = (j / wq) * 8 + (int)(blockIdx.x & 7);
+    if (unit >= p.n_units) return;  // whole workgroup, before any barrier
+    const int qblk = j % wq;
+    const int h = unit % p.H, b = unit / p.H;
+    const int qcol = lane & 15, qg = lane >> 4;
+    const int q0 = (qblk * 8 + wave) * 16 * NQ;
+    int n_valid = p.q_rows_per_batch - q0;  // valid query rows of this wave (<= 0: the wave only helps staging)
+    if (n_valid > 16 * NQ) n_valid = 16 * NQ;
+    const int64_t qrow0 = (int64_t)b * p.q_rows_per_batch + q0;
+
+    half8 qf[NQ][2];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (t * 16 + qcol < n_valid) v = *reinterpret_cast<const half8*>(p.q + (qrow0 + t * 16 + qcol) * p.ldq + h * 64 + ks * 32 + 8 * qg);
+            qf[t][ks] = v;
+        }
+    const int64_t head_base = ((int64_t)b * p.H + h) * (int64_t)p.Tp * 64;
+    // fragment this wave stages for every key block: waves 0..3 -> K fragment `wave`, waves 4..7 -> V fragment `wave - 4`
+    const half_t* my_frag = (wave < 4 ? p.kp : p.vp) + head_base + (int64_t)(wave & 3) * 512 + lane * 8;
+    int n_blocks = p.Tp / 32;
+    if (p.causal) n_blocks = min(n_blocks, (min(p.q_rows_per_batch, (qblk + 1) * 128 * NQ) - 1) / 32 + 1);  // past the workgroup's last query: masked
+    const int my_blocks = (p.causal && n_valid > 0) ? min(n_blocks, (q0 + n_valid - 1) / 32 + 1) : n_blocks;
+
+    floatx4 o[NQ][4];
+    float m_run[NQ], l_run[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        m_run[t] = -INFINITY;
+        l_run[t] = 0.f;
+    }
+#define WRS_ENC_ISSUE(kb_)                                                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(my_frag + (int64_t)(kb_) * 2048),           \
+                                     (__attribute__((address_space(3))) void*)&ring[(kb_) % 3][wave][0], 16, 0, 0)
+    WRS_ENC_ISSUE(0);
+    if (n_blocks > 1) WRS_ENC_ISSUE(1);
+    for (int kb = 0; kb < n_blocks; ++kb) {
+        // block kb has landed (the younger request of block kb+1 stays in flight); every wave is past compute(kb-1)
+        if (kb + 1 < n_blocks) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kb + 2 < n_blocks) WRS_ENC_ISSUE(kb + 2);  // into the slot of block kb-1, which nobody reads any more
+        if (n_valid <= 0 || kb >= my_blocks) continue;
+        half8 kc[4], vc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kc[i] = ring[kb % 3][i][lane];
+            vc[i] = ring[kb % 3][4 + i][lane];
+        }
+        const bool tail = kb * 32 + 32 > p.T;
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            floatx4 s0 = floatx4{0.f, 0.f, 0.f, 0.f}, s1 = floatx4{0.f, 0.f, 0.f, 0.f};
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0], qf[t][0], s0, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1], qf[t][1], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[2], qf[t][0], s1, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[3], qf[t][1], s1, 0, 0, 0);
+            float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            if (tail) {  // tail block: mask padded keys
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int key = kb * 32 + (jj < 4 ? 4 * qg + jj : 16 + 4 * qg + (jj - 4));
+                    if (key >= p.T) sv[jj] = -INFINITY;
+                }
+            }
+            if (p.causal && kb * 32 + 31 > q0 + t * 16) {  // block reaches past the tile's first query: mask key > query
+                const int qi = q0 + t * 16 + qcol;           // (block 0 always holds key 0 <= query: the running max stays finite)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int key = kb * 32 + (jj < 4 ? 4 * qg + jj : 16 + 4 * qg + (jj - 4));
+                    if (key > qi) sv[jj] = -INFINITY;
+                }
+            }
+            float bm = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+            bm = fmaxf(bm, __shfl_xor(bm, 16));
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float m_new = fmaxf(m_run[t], bm);
+            if (__any(m_new != m_run[t])) {  // the running maximum moved for some query of the tile: rescale (rare after the first blocks)
+                const float alpha = __expf(m_run[t] - m_new);
+                l_run[t] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[t][dt] *= alpha;
+                m_run[t] = m_new;
+            }
+            float ps = 0.f;
+            half8 pf;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float e = __expf(sv[jj] - m_new);
+                ps += e;
+                pf[jj] = (_Float16)e;
+            }
+            ps += __shfl_xor(ps, 16);
+            ps += __shfl_xor(ps, 32);
+            l_run[t] += ps;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vc[dt], pf, o[t][dt], 0, 0, 0);
+        }
+    }
+#undef WRS_ENC_ISSUE
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        if (t * 16 + qcol < n_valid) {
+            const float inv = 1.f / l_run[t];
+            half_t* dst = p.out + (qrow0 + t * 16 + qcol) * p.ldo + h * 64 + 4 * qg;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<half4*>(dst + dt * 16) = half4{(_Float16)(o[t][dt][0] * inv), (_Float16)(o[t][dt][1] * inv),
+                                                                 (_Float16)(o[t][dt][2] * inv), (_Float16)(o[t][dt][3] * inv)};
+        }
+    }
+}
+
 void launch_attn_full(const half_t* q, int64_t ldq, const half_t* kp, const half_t* vp, int n_batch, int Tq, int T, int H,
                       half_t* out, int64_t ldo, hipStream_t s, bool causal) {
     WRS_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && T >= 1 && Tq >= 1, "attn_full: bad shape");
@@ -333,6 +467,10 @@ void launch_attn_full(const half_t* q, int64_t ldq, const half_t* kp, const half
     AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, Tq, 0, out, ldo, nullptr, 0, 0, nullptr, 1.f, n_batch * H, causal ? 1 : 0};
     const int64_t units8 = cdiv((int64_t)n_batch * H, 8);
     static const int nq = getenv("WRS_ATTN_NQ") ? atoi(getenv("WRS_ATTN_NQ")) : ENC_ATTN_NQ;
+    static const int lds_mode = getenv("WRS_ATTN_LDS") ? atoi(getenv("WRS_ATTN_LDS")) : 2;  // 0: per-wave K/V streams (round 1); 1/2/4: LDS-shared, NQ tiles per wave
+    if (lds_mode == 4) { attn_enc_kernel<4><<<(unsigned)(8 * units8 * cdiv(Tq, 512)), 512, 0, s>>>(p); return; }
+    if (lds_mode == 2) { attn_enc_kernel<2><<<(unsigned)(8 * units8 * cdiv(Tq, 256)), 512, 0, s>>>(p); return; }
+    if (lds_mode == 1) { attn_enc_kernel<1><<<(unsigned)(8 * units8 * cdiv(Tq, 128)), 512, 0, s>>>(p); return; }
     if (nq == 4) attn_mfma_kernel<false, 4><<<(unsigned)(8 * units8 * cdiv(Tq, 256)), 256, 0, s>>>(p);
     else if (nq == 2) attn_mfma_kernel<false, 2><<<(unsigned)(8 * units8 * cdiv(Tq, 128)), 256, 0, s>>>(p);
     else attn_mfma_kernel<false, 1><<<(unsigned)(8 * units8 * cdiv(Tq, 64)), 256, 0, s>>>(p);
