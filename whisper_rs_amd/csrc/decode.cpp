@@ -309,14 +309,19 @@ void DecodeTask::record_trace(int R) {
 bool DecodeTask::update_beam(int n_audio, bool step0, const float* lp, const int* id) {
     const int G = group, k = G + 1;
     struct Cand { int beam; int64_t token; double score; int source; };
-    std::vector<std::vector<int64_t>> new_rows((size_t)n_audio * G);
-    std::vector<float> new_slp((size_t)n_audio * G, 0.f);
-    std::vector<int> new_src((size_t)n_audio * G, 0);
+    // scratch rows keep their capacity from step to step (1280 rows x 224 steps: no allocation on the step path)
+    std::vector<std::vector<int64_t>>& new_rows = scratch_rows;
+    new_rows.resize((size_t)n_audio * G);
+    std::vector<float>& new_slp = scratch_slp;
+    std::vector<int>& new_src = scratch_src;
+    new_slp.assign((size_t)n_audio * G, 0.f);
+    new_src.assign((size_t)n_audio * G, 0);
     const int max_candidates = (int)round_half_away((double)(patience * (float)G));  // :122
     bool completed = true;
+    std::vector<Cand> cands;
+    cands.reserve((size_t)G * k);
     for (int i = 0; i < n_audio; ++i) {
-        std::vector<Cand> cands;
-        cands.reserve((size_t)G * k);
+        cands.clear();
         for (int j = 0; j < G; ++j) {
             const int idx = i * G + j;
             const int trow = step0 ? i : idx;
@@ -348,7 +353,8 @@ bool DecodeTask::update_beam(int n_audio, bool step0, const float* lp, const int
                 newly.push_back(std::move(f));
             } else {
                 const int dst = i * G + saved;
-                new_rows[dst] = rows[i * G + c.beam];
+                const std::vector<int64_t>& from = rows[i * G + c.beam];
+                new_rows[dst].assign(from.begin(), from.end());  // no allocation: capacity n_ctx + 2 reserved in run_decode
                 new_rows[dst].push_back(c.token);
                 new_slp[dst] = (float)c.score;  // :91-95 stored into the f32 tensor
                 new_src[dst] = c.source;
@@ -486,6 +492,9 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
 
     // host state (decode/mod.rs:297-325)
     rows.assign(R, initial_tokens);
+    scratch_rows.resize(R);
+    for (int r = 0; r < R; ++r) { rows[r].reserve((size_t)m->n_ctx + 2); scratch_rows[r].reserve((size_t)m->n_ctx + 2); }
+    tr_tokens.reserve((size_t)R * sample_len); tr_src.reserve((size_t)R * sample_len); tr_slp.reserve((size_t)R * sample_len);
     if (!audio_lang.empty()) {
         WRS_REQUIRE((int)audio_lang.size() >= n_audio, "run: %d windows but only %d languages set", n_audio, (int)audio_lang.size());
         for (int r = 0; r < R; ++r) rows[r][sot_idx + 1] = audio_lang[r / G];

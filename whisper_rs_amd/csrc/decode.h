@@ -44,6 +44,9 @@ struct DecodeTask {
 
     // host sequencer state
     std::vector<std::vector<int64_t>> rows;  // [R] token history incl. prompt
+    std::vector<std::vector<int64_t>> scratch_rows;  // next step's rows (swapped with `rows`; capacities are kept)
+    std::vector<float> scratch_slp;
+    std::vector<int> scratch_src;
     std::vector<float> sum_logprobs;         // [R] (f32 like the reference's tensor)
     std::vector<int> sources;                // [R]
     std::vector<std::vector<FinishedSeq>> finished;  // per audio, admission order
