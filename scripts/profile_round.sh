@@ -8,14 +8,14 @@ tag=${1:-rXX}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-python3 bench.py --steps 3 --warmup 1 > $out/bench_default.json.log 2>&1 && echo "bench default done" || exit 1
-rocprofv3 --kernel-trace --stats -d $out/prof_seq -o seq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap > $out/bench_under_rocprof_sequential.json.log 2>&1 && echo "trace seq done" || exit 1
-python3 scripts/trace_summary.py $(ls $out/prof_seq/*/*kernel_trace.csv $out/prof_seq/*kernel_trace.csv 2>/dev/null | head -1) > $out/trace_summary_sequential.txt && echo "summary done"
-cp $(ls $out/prof_seq/*/*kernel_stats.csv $out/prof_seq/*kernel_stats.csv 2>/dev/null | head -1) $out/kernel_stats_sequential.csv
-rm -f $out/prof_seq/*/*kernel_trace.csv $out/prof_seq/*kernel_trace.csv
+if [ -z "$SKIP_BENCH" ]; then python3 bench.py --steps 3 --warmup 1 > $out/bench_default.json.log 2>&1 && echo "bench default done" || exit 1; fi
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_seq -o seq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap > $out/bench_under_rocprof_sequential.json.log 2>&1 && echo "trace seq done" || exit 1
+python3 scripts/trace_summary.py $(find $out/prof_seq -name '*kernel_trace.csv' | head -1) > $out/trace_summary_sequential.txt && echo "summary done"
+cp $(find $out/prof_seq -name '*kernel_stats.csv' | head -1) $out/kernel_stats_sequential.csv
+rm -rf $out/prof_seq
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $out/pmc_$c -o pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --sample-len 24 > $out/pmc_$c.log 2>&1 && echo "pmc $c done" || exit 1
-  python3 scripts/pmc_summary.py $(ls $out/pmc_$c/*/*counter_collection.csv $out/pmc_$c/*counter_collection.csv 2>/dev/null | head -1) > $out/pmc_$c.txt
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --sample-len 24 > $out/pmc_$c.log 2>&1 && echo "pmc $c done" || exit 1
+  python3 scripts/pmc_summary.py $(find $out/pmc_$c -name '*counter_collection.csv' | head -1) > $out/pmc_$c.txt
   rm -rf $out/pmc_$c
 done
 ls -la $out

@@ -510,6 +510,21 @@ struct SelfAttnParams {
     const half_t* q16;
 };
 
+// cross-lane adds / maxima inside an 8-lane group and between the two groups of a 16-lane row as DPP modifiers of the
+// VALU instruction itself (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_ror:8) instead of ds_bpermute round trips
+// through the LDS pipeline (what __shfl_xor compiles to): the decode self-attention kernel issues 15 of them per 32 positions
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum8(float x) {  // every lane gets the sum over its 8-lane group
+    x += dpp_f<0xB1>(x);   // lane ^ 1
+    x += dpp_f<0x4E>(x);   // lane ^ 2
+    x += dpp_f<0x141>(x);  // mirror inside 8 lanes: the other quad's total
+    return x;
+}
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ void slab_chunk8(const float* __restrict__ slab, int ksplit, int64_t slab_stride, int64_t off,
                                             const float* __restrict__ bias, int col, float (&o)[8]) {
     floatx4 a0 = *reinterpret_cast<const floatx4*>(slab + off), a1 = *reinterpret_cast<const floatx4*>(slab + off + 4);
@@ -586,12 +601,15 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
 
     // single pass, online softmax.  State per lane: running max m (wave-uniform), partial denominator l and
     // partial output acc[8] over the positions this lane's group g has seen; groups are merged at the end.
+    // q is rounded to fp16 (the cross-attention kernel does the same): scores are v_dot2_f32_f16 products, fp32 accumulate
+    half2_t qh[4];
     float s_new = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s_new += qv[j] * kn[j];
-    s_new += __shfl_xor(s_new, 1);
-    s_new += __shfl_xor(s_new, 2);
-    s_new += __shfl_xor(s_new, 4);
+    for (int j = 0; j < 4; ++j) {
+        qh[j] = half2_t{(_Float16)qv[2 * j], (_Float16)qv[2 * j + 1]};
+        s_new += (float)qh[j][0] * kn[2 * j] + (float)qh[j][1] * kn[2 * j + 1];
+    }
+    s_new = sum8(s_new);
     float m_run = s_new;  // the new position seeds the running max (weight exp(0) = 1), counted once by group 0
     float l_run = (g == 0) ? 1.f : 0.f;
     float acc[8];
@@ -619,15 +637,14 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
         for (int u = 0; u < 4; ++u) {
             float x = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x += qv[j] * (float)kv[u][j];
-            x += __shfl_xor(x, 1);
-            x += __shfl_xor(x, 2);
-            x += __shfl_xor(x, 4);
+            for (int j = 0; j < 4; ++j) x = __builtin_amdgcn_fdot2(qh[j], half2_t{kv[u][2 * j], kv[u][2 * j + 1]}, x, false);
+            x = sum8(x);
             t[u] = ok[u] ? x : -INFINITY;
             cm = fmaxf(cm, t[u]);
         }
+        cm = fmaxf(cm, dpp_f<0x128>(cm));  // row_ror:8: the other 8-lane group of the 16-lane row
 #pragma unroll
-        for (int o = 8; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o));
+        for (int o = 16; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o));
         const float m_new = fmaxf(m_run, cm);
         const float alpha = __expf(m_run - m_new);
         l_run *= alpha;
