@@ -524,6 +524,7 @@ __device__ __forceinline__ float sum8(float x) {  // every lane gets the sum ove
     return x;
 }
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef int intx4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void slab_chunk8(const float* __restrict__ slab, int ksplit, int64_t slab_stride, int64_t off,
                                             const float* __restrict__ bias, int col, float (&o)[8]) {
@@ -616,6 +617,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = (g == 0) ? vn[j] : 0.f;
 
+    const unsigned row_stride_b = (unsigned)(p.n_ctx * D * 2);
     for (int p0 = 0; p0 < cpos; p0 += 32) {
         half8 kv[4], vv[4];
         bool ok[4];
@@ -626,9 +628,11 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
             kv[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
             vv[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
             if (ok[u]) {
-                const int64_t off = (int64_t)anc_s[pos] * row_stride + (int64_t)pos * D + col;
-                kv[u] = *reinterpret_cast<const half8*>(p.kc + off);
-                vv[u] = *reinterpret_cast<const half8*>(p.vc + off);
+                // 32-bit byte offset from the (wave-uniform) cache base: one v_mad_u32_u24 + add per load instead of 64-bit
+                // pointer arithmetic (a layer's cache is < 4 GiB: checked by the launcher)
+                const unsigned boff = (unsigned)anc_s[pos] * row_stride_b + (unsigned)pos * (unsigned)(D * 2) + (unsigned)(col * 2);
+                kv[u] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.kc) + boff);
+                vv[u] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.vc) + boff);
             }
         }
         float t[4];
@@ -654,8 +658,13 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
         for (int u = 0; u < 4; ++u) {
             const float w = __expf(t[u] - m_new);  // exp(-inf) = 0 for padded slots
             l_run += w;
+            // acc += w * v with the fp16 -> fp32 conversion inside the FMA (v_fma_mix_f32: 8 instructions instead of 8 cvt + 8 fma)
+            const intx4 vi = __builtin_bit_cast(intx4, vv[u]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += w * (float)vv[u][j];
+            for (int j = 0; j < 4; ++j) {
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * j]) : "v"(vi[j]), "v"(w));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * j + 1]) : "v"(vi[j]), "v"(w));
+            }
         }
         m_run = m_new;
     }
@@ -679,6 +688,7 @@ void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float*
                       const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, int rows_per_audio, int phys_mul, int H, int D,
                       const StepParams* sp, half_t* out, hipStream_t s) {
     WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && qkv_slab && qkv_bias && ksplit >= 1, "attn_self: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
+    WRS_REQUIRE((int64_t)n_rows * phys_mul * n_ctx * D * 2 < (1ll << 32), "attn_self: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
     WRS_REQUIRE(rows_per_audio >= 1 && n_rows % rows_per_audio == 0, "attn_self: rows %d not a multiple of %d", n_rows, rows_per_audio);
     SelfAttnParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio, nullptr};
     const int64_t units = (int64_t)(n_rows / rows_per_audio) * ((H + 3) / 4);
@@ -689,6 +699,7 @@ void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float*
 void launch_attn_self_q16(const half_t* q16, half_t* kc, half_t* vc, const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows,
                           int rows_per_audio, int phys_mul, int H, int D, const StepParams* sp, half_t* out, hipStream_t s) {
     WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && q16, "attn_self: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
+    WRS_REQUIRE((int64_t)n_rows * phys_mul * n_ctx * D * 2 < (1ll << 32), "attn_self: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
     WRS_REQUIRE(rows_per_audio >= 1 && n_rows % rows_per_audio == 0, "attn_self: rows %d not a multiple of %d", n_rows, rows_per_audio);
     SelfAttnParams p{nullptr, 1, 0, nullptr, 1.f, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio, q16};
     const int64_t units = (int64_t)(n_rows / rows_per_audio) * ((H + 3) / 4);

@@ -157,19 +157,22 @@ void launch_layernorm_packed(const float* x, const float* g, const float* b, int
 // One 256-thread workgroup per row: parallelism comes from splitting the row, and all ksplit slab loads of a thread are
 // independent and in flight together.  (A wave-per-row variant — no LDS, no barrier — was measured 2 % slower on the
 // whole decode at 1280 rows.)
-template <int NV>  // float4 vectors per thread: D <= 1024 * NV
-__global__ __launch_bounds__(256) void finish_residual_ln_kernel(float* __restrict__ x, const float* __restrict__ slab,
-                                                                 int ksplit, int m_pad, const float* __restrict__ bias,
-                                                                 const float* __restrict__ g, const float* __restrict__ b,
-                                                                 int M, int D, half_t* __restrict__ xn) {
-    __shared__ float red[8];
+// NT threads per row: every thread owns float4 vectors c = (i * NT + tid) * 4 < D.  NT = D / 4 when that is a whole number of
+// waves (D = 1280: 320 threads, one vector each, nobody idle; the 256-thread form left 3 of 4 waves with half the work).
+template <int NV, int NT>
+__global__ __launch_bounds__(NT) void finish_residual_ln_kernel(float* __restrict__ x, const float* __restrict__ slab,
+                                                                int ksplit, int m_pad, const float* __restrict__ bias,
+                                                                const float* __restrict__ g, const float* __restrict__ b,
+                                                                int M, int D, half_t* __restrict__ xn) {
+    constexpr int NW = NT / 64;
+    __shared__ float red[2 * NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x;
     floatx4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = (i * 256 + tid) * 4;
+        const int c = (i * NT + tid) * 4;
         v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
         if (c < D) {
             floatx4 acc = *reinterpret_cast<const floatx4*>(slab + (int64_t)row * D + c);
@@ -186,11 +189,14 @@ __global__ __launch_bounds__(256) void finish_residual_ln_kernel(float* __restri
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
-    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)D;
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[w];
+    const float mean = tot / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = (i * 256 + tid) * 4;
+        const int c = (i * NT + tid) * 4;
         if (c < D) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -200,12 +206,15 @@ __global__ __launch_bounds__(256) void finish_residual_ln_kernel(float* __restri
         }
     }
     q = wave_sum(q);
-    if (lane == 0) red[4 + wave] = q;
+    if (lane == 0) red[NW + wave] = q;
     __syncthreads();
-    const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)D + 1e-5f);
+    float qt = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) qt += red[NW + w];
+    const float rstd = rsqrtf(qt / (float)D + 1e-5f);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = (i * 256 + tid) * 4;
+        const int c = (i * NT + tid) * 4;
         if (c < D) {
             const floatx4 gg = *reinterpret_cast<const floatx4*>(g + c);
             const floatx4 bb = *reinterpret_cast<const floatx4*>(b + c);
@@ -220,8 +229,10 @@ __global__ __launch_bounds__(256) void finish_residual_ln_kernel(float* __restri
 void launch_finish_residual_ln(float* x, const float* slab, int ksplit, int m_pad, const float* bias, const float* g,
                                const float* b, int M, int D, half_t* xn, hipStream_t s) {
     WRS_REQUIRE(D % 32 == 0 && D <= 2048, "finish_residual_ln: D=%d unsupported", D);
-    if (D <= 1024) finish_residual_ln_kernel<1><<<M, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
-    else finish_residual_ln_kernel<2><<<M, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
+    if (D == 1280) finish_residual_ln_kernel<1, 320><<<M, 320, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
+    else if (D == 768) finish_residual_ln_kernel<1, 192><<<M, 192, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
+    else if (D <= 1024) finish_residual_ln_kernel<1, 256><<<M, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
+    else finish_residual_ln_kernel<2, 256><<<M, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
 }
 
 // MLP-1 finish: split-K reduction + bias + exact GELU (reference model.rs:279-286) -> packed fp16 activations
