@@ -659,12 +659,20 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
             const float w = __expf(t[u] - m_new);  // exp(-inf) = 0 for padded slots
             l_run += w;
             // acc += w * v with the fp16 -> fp32 conversion inside the FMA (v_fma_mix_f32: 8 instructions instead of 8 cvt + 8 fma)
+            // (the s_nop covers the transcendental-result hazard: w comes straight from v_exp_f32 and the compiler does not
+            // see VALU consumers inside inline asm)
             const intx4 vi = __builtin_bit_cast(intx4, vv[u]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * j]) : "v"(vi[j]), "v"(w));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * j + 1]) : "v"(vi[j]), "v"(w));
-            }
+            asm("s_nop 1\n\t"
+                "v_fma_mix_f32 %0, %8, %12, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %1, %8, %12, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %2, %9, %12, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %3, %9, %12, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %4, %10, %12, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %5, %10, %12, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %6, %11, %12, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %7, %11, %12, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                : "v"(vi[0]), "v"(vi[1]), "v"(vi[2]), "v"(vi[3]), "v"(w));
         }
         m_run = m_new;
     }
