@@ -11,8 +11,8 @@
 //   topk(beam+1)       (extractor/beam_search.rs:62-65), argmax (greedy.rs:25)
 //   no-speech prob     (decode/mod.rs:250-255) softmax(raw logits)[no_speech] at step 0
 // One 256-thread workgroup per row; every reduction is a 64-lane wave reduction followed by a
-// 4-wave LDS combine.  The row (207 KB f32) is streamed from L2 three times; nothing is written
-// back except k (logprob, id) pairs.
+// 4-wave LDS combine.  The row (207 KB f32) is read ONCE with 16-byte loads (online max / sum-exp and per-thread top-8
+// lists for the text and the timestamp range); nothing is written back except k (logprob, id) pairs.
 #include "kernels.h"
 
 namespace wrs {
@@ -60,6 +60,26 @@ struct FilterParams {
     float* out_filtered;
 };
 
+// insertion of (cv, ci) into a list sorted by value descending, index ascending on ties (static indexing: registers)
+__device__ __forceinline__ void topk_insert(float (&tv)[TOPK_MAX], int (&ti)[TOPK_MAX], float cv, int ci) {
+#pragma unroll
+    for (int j = 0; j < TOPK_MAX; ++j) {
+        const bool better = cv > tv[j] || (cv == tv[j] && ci < ti[j]);
+        if (better) {
+            const float ov = tv[j];
+            const int oi = ti[j];
+            tv[j] = cv;
+            ti[j] = ci;
+            cv = ov;
+            ci = oi;
+        }
+    }
+}
+
+// ONE pass over the row (round 1 streamed it three times with 4-byte loads): 16-byte loads, and for each of the two index
+// ranges the timestamp rule distinguishes — text [0, ts_begin) and timestamps [ts_begin, V) — an online (max, sum-exp)
+// pair and a per-thread top-8 list.  The rule's decision (timestamp_tokens.rs:83-96) then only picks which lists and
+// which normaliser apply; nothing has to be re-read.
 __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) {
     extern __shared__ unsigned int smem[];  // bitmask of statically suppressed ids: ceil(V/32) words
     __shared__ float red[4];
@@ -70,17 +90,7 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
     const float* x = p.logits + (int64_t)row * p.ld;
     const int first = p.sp->first_step;
     const int nwords = (V + 31) / 32;
-
-    // ---- no-speech probability on the raw logits (decode/mod.rs:250-255)
-    if (p.sp->want_no_speech && p.no_speech_out) {
-        float m = -INFINITY;
-        for (int v = tid; v < V; v += 256) m = fmaxf(m, x[v]);
-        m = block_max(m, red);
-        float su = 0.f;
-        for (int v = tid; v < V; v += 256) su += __expf(x[v] - m);
-        su = block_add(su, red);
-        if (tid == 0) p.no_speech_out[row] = __expf(x[p.no_speech] - m) / su;
-    }
+    const bool want_ns = p.sp->want_no_speech && p.no_speech_out;
 
     // ---- static suppression mask
     for (int w = tid; w < nwords; w += 256) smem[w] = 0u;
@@ -111,47 +121,75 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
     }
     const int tsb = p.timestamps ? p.ts_begin : V;
 
-    // ---- pass A: maxima of the text and timestamp ranges
-    float mt = -INFINITY, ms = -INFINITY;
-    for (int v = tid; v < V; v += 256) {
-        float val = x[v];
-        if (v < lo || v >= hi || ((smem[v >> 5] >> (v & 31)) & 1u)) val = -INFINITY;
-        if (v < tsb) mt = fmaxf(mt, val);
-        else ms = fmaxf(ms, val);
+    // ---- the pass
+    float mt = -INFINITY, st = 0.f, ms = -INFINITY, ss = 0.f;  // text / timestamp ranges: running max, sum of exp(val - max)
+    float mr = -INFINITY, sr = 0.f;                            // raw logits (no-speech probability, step 0 only)
+    float tvt[TOPK_MAX], tvs[TOPK_MAX];
+    int tit[TOPK_MAX], tis[TOPK_MAX];
+#pragma unroll
+    for (int j = 0; j < TOPK_MAX; ++j) {
+        tvt[j] = tvs[j] = -INFINITY;
+        tit[j] = tis[j] = 0x7fffffff;
     }
-    mt = block_max(mt, red);
-    ms = block_max(ms, red);
-    const float mall = fmaxf(mt, ms);
-
-    // ---- pass B: sum-exp of both ranges relative to the global max (log_softmax, timestamp_tokens.rs:82)
-    float st = 0.f, ss = 0.f, ss_own = 0.f;
-    for (int v = tid; v < V; v += 256) {
-        float val = x[v];
-        if (v < lo || v >= hi || ((smem[v >> 5] >> (v & 31)) & 1u)) val = -INFINITY;
-        if (v < tsb) st += __expf(val - mall);
-        else {
-            ss += __expf(val - mall);
-            if (val != -INFINITY) ss_own += __expf(val - ms);  // (-inf) - (-inf) would be NaN when the range is empty
+    typedef float floatx4 __attribute__((ext_vector_type(4)));
+    const bool vec_ok = (p.ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.logits) & 15) == 0);
+    for (int v0 = tid * 4; v0 < V; v0 += 1024) {
+        float val4[4];
+        if (vec_ok && v0 + 4 <= p.ld) {
+            const floatx4 t = *reinterpret_cast<const floatx4*>(x + v0);
+            val4[0] = t[0]; val4[1] = t[1]; val4[2] = t[2]; val4[3] = t[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val4[e] = v0 + e < V ? x[v0 + e] : -INFINITY;
+        }
+        const unsigned bits = smem[v0 >> 5] >> (v0 & 31);  // 4 consecutive ids never straddle a 32-bit word (v0 % 4 == 0)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int v = v0 + e;
+            if (v >= V) continue;
+            float val = val4[e];
+            if (want_ns) {  // softmax of the RAW logits (decode/mod.rs:250-255)
+                if (val > mr) { sr = sr * __expf(mr - val) + 1.f; mr = val; }
+                else sr += __expf(val - mr);
+            }
+            if (v < lo || v >= hi || ((bits >> e) & 1u)) continue;
+            if (v < tsb) {
+                if (val > mt) { st = st * __expf(mt - val) + 1.f; mt = val; }
+                else st += __expf(val - mt);
+                if (val > tvt[TOPK_MAX - 1] || (val == tvt[TOPK_MAX - 1] && v < tit[TOPK_MAX - 1])) topk_insert(tvt, tit, val, v);
+            } else {
+                if (val > ms) { ss = ss * __expf(ms - val) + 1.f; ms = val; }
+                else ss += __expf(val - ms);
+                if (val > tvs[TOPK_MAX - 1] || (val == tvs[TOPK_MAX - 1] && v < tis[TOPK_MAX - 1])) topk_insert(tvs, tis, val, v);
+            }
         }
     }
-    st = block_add(st, red);
-    ss = block_add(ss, red);
-    ss_own = block_add(ss_own, red);
-
+    // ---- combine the threads' (max, sum) pairs
+    if (want_ns) {
+        const float Mr = block_max(mr, red);
+        const float Sr = block_add(mr == -INFINITY ? 0.f : sr * __expf(mr - Mr), red);
+        if (tid == 0) p.no_speech_out[row] = __expf(x[p.no_speech] - Mr) / Sr;
+    }
+    const float Mt = block_max(mt, red);
+    const float St = block_add(mt == -INFINITY ? 0.f : st * __expf(mt - Mt), red);  // sum over text of exp(val - Mt)
+    const float Ms = block_max(ms, red);
+    const float Ss = block_add(ms == -INFINITY ? 0.f : ss * __expf(ms - Ms), red);  // sum over timestamps of exp(val - Ms)
+    const float mall = fmaxf(Mt, Ms);
+    const float tot = (Mt == -INFINITY ? 0.f : St * __expf(Mt - mall)) + (Ms == -INFINITY ? 0.f : Ss * __expf(Ms - mall));
     bool mask_text = false;
-    float lse = mall + __logf(st + ss);
+    float lse = mall + __logf(tot);  // log_softmax normaliser (timestamp_tokens.rs:82)
     if (p.timestamps) {
         // timestamp_tokens.rs:83-96: logsumexp(logprobs[ts_begin:]) > max(logprobs[:ts_begin]) ?
-        const float ts_lp = (ms == -INFINITY) ? -INFINITY : (ms - lse) + __logf(ss_own);
-        const float text_lp = mt - lse;
+        const float ts_lp = (Ms == -INFINITY) ? -INFINITY : (Ms - lse) + __logf(Ss);
+        const float text_lp = Mt - lse;
         if (ts_lp > text_lp) {
             mask_text = true;
-            lse = ms + __logf(ss_own);  // log_softmax after masking the text range (beam_search.rs:37)
+            lse = Ms + __logf(Ss);  // log_softmax after masking the text range (beam_search.rs:37)
         }
     }
     if (mask_text) lo = max(lo, p.ts_begin);
 
-    if (p.out_filtered) {
+    if (p.out_filtered) {  // test hook only
         float* o = p.out_filtered + (int64_t)row * V;
         for (int v = tid; v < V; v += 256) {
             float val = x[v];
@@ -160,37 +198,22 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
         }
     }
 
-    // ---- pass C: top-k.  Each thread keeps its TOPK_MAX best (value desc, index asc on ties), then k rounds
-    // of block arg-max over the threads' current heads.
+    // ---- top-k.  The thread's candidates: its timestamp list, plus its text list unless the rule masked the text range
+    // (text ids are all below timestamp ids, so the merged order keeps "index ascending on ties").  Then k rounds of block
+    // arg-max over the threads' current heads.
     float tv[TOPK_MAX];
     int ti[TOPK_MAX];
 #pragma unroll
     for (int j = 0; j < TOPK_MAX; ++j) {
-        tv[j] = -INFINITY;
-        ti[j] = 0x7fffffff;
+        tv[j] = tvs[j];
+        ti[j] = tis[j];
+    }
+    if (!mask_text) {
+#pragma unroll
+        for (int j = 0; j < TOPK_MAX; ++j)
+            if (tit[j] != 0x7fffffff) topk_insert(tv, ti, tvt[j], tit[j]);
     }
     const int K = p.k;
-    for (int v = tid; v < V; v += 256) {
-        float val = x[v];
-        if (v < lo || v >= hi || ((smem[v >> 5] >> (v & 31)) & 1u)) continue;
-        if (val > tv[TOPK_MAX - 1] || (val == tv[TOPK_MAX - 1] && v < ti[TOPK_MAX - 1])) {
-            // insertion into the sorted list (static indexing keeps tv/ti in registers)
-            float cv = val;
-            int ci = v;
-#pragma unroll
-            for (int j = 0; j < TOPK_MAX; ++j) {
-                const bool better = cv > tv[j] || (cv == tv[j] && ci < ti[j]);
-                if (better) {
-                    const float ov = tv[j];
-                    const int oi = ti[j];
-                    tv[j] = cv;
-                    ti[j] = ci;
-                    cv = ov;
-                    ci = oi;
-                }
-            }
-        }
-    }
     int head = 0;
     for (int round = 0; round < K; ++round) {
         float hv = -INFINITY;
