@@ -22,6 +22,27 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// cross-lane adds / maxima inside an 8-lane group and between the two groups of a 16-lane row as DPP modifiers of the
+// VALU instruction itself (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_ror:8) instead of ds_bpermute round trips
+// through the LDS pipeline (what __shfl_xor compiles to): the decode self-attention kernel issues 15 of them per 32 positions
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// max over the lanes l, l^16, l^32, l^48 with v_permlane16_swap / v_permlane32_swap (gfx950 VALU row swaps) instead of two
+// ds_bpermute round trips through the LDS pipeline
+__device__ __forceinline__ float max_rows(float x) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float sum8(float x) {  // every lane gets the sum over its 8-lane group
+    x += dpp_f<0xB1>(x);   // lane ^ 1
+    x += dpp_f<0x4E>(x);   // lane ^ 2
+    x += dpp_f<0x141>(x);  // mirror inside 8 lanes: the other quad's total
+    return x;
+}
 size_t packed_kv_halfs_per_head(int T) { return (size_t)round_up(T, 32) * 64; }
 
 // ------------------------------------------------------------------------------------------ pack
@@ -369,14 +390,15 @@ __global__ __launch_bounds__(512) void attn_enc_kernel(const AttnParams p) {
     if (p.causal) n_blocks = min(n_blocks, (min(p.q_rows_per_batch, (qblk + 1) * 128 * NQ) - 1) / 32 + 1);  // past the workgroup's last query: masked
     const int my_blocks = (p.causal && n_valid > 0) ? min(n_blocks, (q0 + n_valid - 1) / 32 + 1) : n_blocks;
 
-    floatx4 o[NQ][4];
-    float m_run[NQ], l_run[NQ];
+    floatx4 o[NQ][4], lsum[NQ];  // lsum: the softmax denominator, accumulated by a fifth MFMA against a fragment of ones
+    float m_run[NQ];
+    const half8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[t][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        lsum[t] = floatx4{0.f, 0.f, 0.f, 0.f};
         m_run[t] = -INFINITY;
-        l_run[t] = 0.f;
     }
 #define WRS_ENC_ISSUE(kb_)                                                                                                     \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(my_frag + (int64_t)(kb_) * 2048),           \
@@ -421,36 +443,30 @@ __global__ __launch_bounds__(512) void attn_enc_kernel(const AttnParams p) {
                 }
             }
             float bm = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-            bm = fmaxf(bm, __shfl_xor(bm, 16));
-            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            bm = max_rows(bm);
             const float m_new = fmaxf(m_run[t], bm);
             if (__any(m_new != m_run[t])) {  // the running maximum moved for some query of the tile: rescale (rare after the first blocks)
                 const float alpha = __expf(m_run[t] - m_new);
-                l_run[t] *= alpha;
+                lsum[t] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) o[t][dt] *= alpha;
                 m_run[t] = m_new;
             }
-            float ps = 0.f;
             half8 pf;
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const float e = __expf(sv[jj] - m_new);
-                ps += e;
-                pf[jj] = (_Float16)e;
-            }
-            ps += __shfl_xor(ps, 16);
-            ps += __shfl_xor(ps, 32);
-            l_run[t] += ps;
+            for (int jj = 0; jj < 8; ++jj) pf[jj] = (_Float16)__expf(sv[jj] - m_new);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vc[dt], pf, o[t][dt], 0, 0, 0);
+            // sum_k P[k][q] for every output row: each lane ends up with its query column's denominator (of the fp16-rounded
+            // weights, i.e. exactly the weights the P.V product used)
+            lsum[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf, lsum[t], 0, 0, 0);
         }
     }
 #undef WRS_ENC_ISSUE
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
         if (t * 16 + qcol < n_valid) {
-            const float inv = 1.f / l_run[t];
+            const float inv = 1.f / lsum[t][0];
             half_t* dst = p.out + (qrow0 + t * 16 + qcol) * p.ldo + h * 64 + 4 * qg;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
@@ -510,19 +526,6 @@ struct SelfAttnParams {
     const half_t* q16;
 };
 
-// cross-lane adds / maxima inside an 8-lane group and between the two groups of a 16-lane row as DPP modifiers of the
-// VALU instruction itself (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_ror:8) instead of ds_bpermute round trips
-// through the LDS pipeline (what __shfl_xor compiles to): the decode self-attention kernel issues 15 of them per 32 positions
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float sum8(float x) {  // every lane gets the sum over its 8-lane group
-    x += dpp_f<0xB1>(x);   // lane ^ 1
-    x += dpp_f<0x4E>(x);   // lane ^ 2
-    x += dpp_f<0x141>(x);  // mirror inside 8 lanes: the other quad's total
-    return x;
-}
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef int intx4 __attribute__((ext_vector_type(4)));
 
@@ -647,8 +650,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
             cm = fmaxf(cm, t[u]);
         }
         cm = fmaxf(cm, dpp_f<0x128>(cm));  // row_ror:8: the other 8-lane group of the 16-lane row
-#pragma unroll
-        for (int o = 16; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o));
+        cm = max_rows(cm);
         const float m_new = fmaxf(m_run, cm);
         const float alpha = __expf(m_run - m_new);
         l_run *= alpha;
