@@ -1010,6 +1010,161 @@ void launch_gemm_dec(const half_t* a, const half_t* w_packed, int M, int64_t N, 
     }
 }
 
+// ------------------------------------------------------------------------------------------ decode GEMM with a fused producer (<= 16 rows)
+// One window (beam 5 -> 5 rows) is the reference's own usage mode (TranscribeTask::run decodes window after window), and
+// there a decode step is launch-bound: 12 dependent launches per layer at ~6.5 us each against 0.25 ms of weight stream per
+// step.  For up to 16 rows (one MFMA row tile) the "finish" kernels disappear into the NEXT GEMM's prologue: every
+// workgroup rebuilds the activation fragments of its k-slice itself —
+//   DECF_LN    x_new = x_in + bias_in + sum_s slab_in[s]   (split-K reduction of the previous GEMM + residual, model.rs:302-318),
+//              a = LayerNorm(x_new) * g + b (full-row statistics, two passes, fp32); the workgroups of n-tile group 0 write
+//              x_new to x_out (ping-pong with x_in: other workgroups are still reading x_in)
+//   DECF_GELU  a = gelu(sum_s slab_in[s] + bias_in)          (MLP-1 finish, model.rs:279-286)
+// — from a few KB of L2-resident data (5 rows), so the redundancy costs nothing; 12 launches per layer become 8.
+enum { DECF_LN = 0, DECF_GELU = 1 };
+struct DecFusedParams {
+    const half_t* wp;
+    float* slab;              // out: [ksteps / KPS][16][N]
+    int M, N, ksteps;
+    // producer
+    const float* slab_in;     // [ksplit_in][m_pad_in][K]
+    int ksplit_in, m_pad_in;
+    const float* bias_in;     // [K]
+    const float* x_in;        // DECF_LN: [M, K] fp32
+    float* x_out;             // DECF_LN: [M, K] fp32 (!= x_in)
+    const float* ln_g;
+    const float* ln_b;
+};
+
+template <int KPS, int MODE>
+__global__ __launch_bounds__(256) void gemm_dec_fused_kernel(const DecFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char decf_smem[];
+    half8* wlds = reinterpret_cast<half8*>(decf_smem);            // [4 waves * KPS][64]
+    half8* alds = wlds + (size_t)4 * KPS * 64;                     // [KPS][64]
+    __shared__ float stat_mean[16], stat_rstd[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ntile = blockIdx.x * 4 + wave;
+    const int ks0 = blockIdx.y * KPS;
+    const int K = p.ksteps * 32;
+
+    // this wave's weight fragments: requested first, they land while the activations are rebuilt
+    const half_t* wbase = p.wp + ((int64_t)ntile * p.ksteps + ks0) * 512 + lane * 8;
+#pragma unroll
+    for (int i = 0; i < KPS; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + (int64_t)i * 512),
+                                         (__attribute__((address_space(3))) void*)(wlds + (size_t)(wave * KPS + i) * 64), 16, 0, DEC_W_AUX);
+
+    // value of the producer's output at (row m, columns k .. k+3)
+    auto produced4 = [&](int m, int k) -> floatx4 {
+        floatx4 a = *reinterpret_cast<const floatx4*>(p.slab_in + (int64_t)m * K + k);
+        for (int sidx = 1; sidx < p.ksplit_in; ++sidx) a += *reinterpret_cast<const floatx4*>(p.slab_in + ((int64_t)sidx * p.m_pad_in + m) * K + k);
+        a += *reinterpret_cast<const floatx4*>(p.bias_in + k);
+        if (MODE == DECF_LN) a += *reinterpret_cast<const floatx4*>(p.x_in + (int64_t)m * K + k);
+        return a;
+    };
+    if (MODE == DECF_LN) {
+        // full-row LayerNorm statistics (eps 1e-5, two passes like layernorm_kernel): 16 threads per row
+        const int r = tid >> 4, sub = tid & 15;
+        float mean = 0.f, rstd = 0.f;
+        if (r < p.M) {
+            float sacc = 0.f;
+            for (int k = sub * 4; k < K; k += 64) {
+                const floatx4 a = produced4(r, k);
+                sacc += (a[0] + a[1]) + (a[2] + a[3]);
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sacc += __shfl_xor(sacc, o);
+            mean = sacc / (float)K;
+            float q = 0.f;
+            for (int k = sub * 4; k < K; k += 64) {
+                const floatx4 a = produced4(r, k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = a[e] - mean;
+                    q += d * d;
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
+            rstd = rsqrtf(q / (float)K + 1e-5f);
+        }
+        if (sub == 0) { stat_mean[r] = mean; stat_rstd[r] = rstd; }
+        __syncthreads();
+    }
+    // activation fragments of this k-slice in MFMA B-operand order: fragment kk, lane l holds A[l & 15][(ks0+kk)*32 + 8*(l>>4) .. +7]
+    for (int kk = wave; kk < KPS; kk += 4) {
+        const int m = lane & 15, k0 = (ks0 + kk) * 32 + 8 * (lane >> 4);
+        half8 h = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (m < p.M) {
+            const floatx4 a0 = produced4(m, k0), a1 = produced4(m, k0 + 4);
+            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            if (MODE == DECF_LN) {
+                if (blockIdx.x == 0) {  // one workgroup per k-slice publishes the new residual stream
+                    *reinterpret_cast<floatx4*>(p.x_out + (int64_t)m * K + k0) = a0;
+                    *reinterpret_cast<floatx4*>(p.x_out + (int64_t)m * K + k0 + 4) = a1;
+                }
+                const float mean = stat_mean[m], rstd = stat_rstd[m];
+                const floatx4 g0 = *reinterpret_cast<const floatx4*>(p.ln_g + k0), g1 = *reinterpret_cast<const floatx4*>(p.ln_g + k0 + 4);
+                const floatx4 b0 = *reinterpret_cast<const floatx4*>(p.ln_b + k0), b1 = *reinterpret_cast<const floatx4*>(p.ln_b + k0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (v[e] - mean) * rstd * g0[e] + b0[e];
+                    v[4 + e] = (v[4 + e] - mean) * rstd * g1[e] + b1[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_exact(v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
+        }
+        alds[(size_t)kk * 64 + lane] = h;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // weight fragments landed, activation fragments written
+
+    floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KPS; ++i) {
+        const half8 wf = wlds[(size_t)(wave * KPS + i) * 64 + lane];
+        const half8 af = alds[(size_t)i * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af, acc, 0, 0, 0);
+    }
+    const int n = ntile * 16 + 4 * (lane >> 4);
+    if (n < p.N && (lane & 15) < p.M)
+        *reinterpret_cast<floatx4*>(p.slab + ((int64_t)blockIdx.y * 16 + (lane & 15)) * p.N + n) = acc;
+}
+
+template <int KPS, int MODE>
+static void launch_decf(const DecFusedParams& p, int n_pad, hipStream_t s) {
+    const size_t shmem = (size_t)(1 + 4) * KPS * 1024;
+    static std::atomic<bool> attr_set[64];
+    allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_dec_fused_kernel<KPS, MODE>), shmem, attr_set);
+    dim3 grid((unsigned)(n_pad / 64), (unsigned)(p.ksteps / KPS));
+    gemm_dec_fused_kernel<KPS, MODE><<<grid, 256, shmem, s>>>(p);
+}
+
+// slab[ks][16][N] = A W^T with A rebuilt in the prologue (mode 0: finish + LayerNorm, mode 1: finish + GELU); M <= 16 rows.
+// Returns the number of slabs written (= gemm_dec_plan of the shape).
+int launch_gemm_dec_fused(int mode, const float* slab_in, int ksplit_in, int m_pad_in, const float* bias_in, const float* x_in, float* x_out,
+                          const float* ln_g, const float* ln_b, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K, float* slab,
+                          hipStream_t s) {
+    WRS_REQUIRE(M >= 1 && M <= 16, "gemm_dec_fused: %d rows (at most 16)", M);
+    WRS_REQUIRE(K % 64 == 0 && n_pad % 64 == 0 && N <= n_pad && N % 4 == 0, "gemm_dec_fused: bad shape N=%ld n_pad=%ld K=%ld", (long)N, (long)n_pad, (long)K);
+    WRS_REQUIRE(slab_in && bias_in && ksplit_in >= 1 && m_pad_in >= M && slab, "gemm_dec_fused: bad producer arguments");
+    if (mode == DECF_LN) WRS_REQUIRE(x_in && x_out && x_in != x_out && ln_g && ln_b, "gemm_dec_fused: LN mode needs x_in != x_out and the LayerNorm parameters");
+    int kps = 0, mt = 0;
+    const int ksplit = gemm_dec_plan(M, N, K, &kps, &mt);
+    WRS_REQUIRE(mt == 1, "gemm_dec_fused: unexpected row tiling");
+    DecFusedParams p{w_packed, slab, M, (int)N, (int)(K / 32), slab_in, ksplit_in, m_pad_in, bias_in, x_in, x_out, ln_g, ln_b};
+    switch (kps) {
+#define WRS_DF(K_) case K_: if (mode == DECF_LN) launch_decf<K_, DECF_LN>(p, (int)n_pad, s); else launch_decf<K_, DECF_GELU>(p, (int)n_pad, s); break;
+        WRS_DF(1) WRS_DF(2) WRS_DF(3) WRS_DF(4) WRS_DF(5) WRS_DF(6) WRS_DF(8) WRS_DF(10) WRS_DF(16)
+#undef WRS_DF
+        default: WRS_THROW(WRS_EINVAL, "gemm_dec_fused: unsupported k-steps per workgroup %d", kps);
+    }
+    return ksplit;
+}
+
 // ------------------------------------------------------------------------------------------ f32 GEMM
 __device__ __forceinline__ int float_order_key(float f) {
     const int i = __float_as_int(f);

@@ -139,6 +139,12 @@ int skinny_m_pad(int M);
 int gemm_dec_plan(int M, int64_t N, int64_t K, int* kps_out, int* mt_block_out);
 void launch_gemm_dec(const half_t* a, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K, float* slab, hipStream_t s);
 
+// decode GEMM for <= 16 rows with the producer fused into its prologue (gemm.hip): mode 0 = split-K finish + residual +
+// LayerNorm (x_out = x_in + bias_in + sum slab_in; A = LN(x_out)), mode 1 = split-K finish + bias + GELU.  Returns the slabs written.
+int launch_gemm_dec_fused(int mode, const float* slab_in, int ksplit_in, int m_pad_in, const float* bias_in, const float* x_in, float* x_out,
+                          const float* ln_g, const float* ln_b, const half_t* w_packed, int M, int64_t N, int64_t n_pad, int64_t K, float* slab,
+                          hipStream_t s);
+
 // ---------------------------------------------------------------- f32 GEMM (f32 parity mode)
 // mode 2 (f32 parity mode, parity_f32.hip): C[crow(m)][n] = act((acc + bias[n]) * (n < scale_n_end ? scale : 1)) + posemb + residual
 struct GemmF32Epi {

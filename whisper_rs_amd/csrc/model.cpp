@@ -450,6 +450,8 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.att.alloc((size_t)st.act_rows * D * 2);
     st.h.alloc((size_t)st.act_rows * 4 * D * 2);
     st.q16.alloc((size_t)st.act_rows * D * 2);
+    st.slab2.alloc((size_t)40 * 16 * 4 * D * 4);
+    st.x2.alloc((size_t)16 * D * 4);
     st.slab.alloc((size_t)40 * m_pad * 4 * D * 4);  // ksplit (<= K/32 <= 40 for N = 4D; <= 160 for N = D) * m_pad * N floats
     st.logits_ld = (int)round_up(V, 8);  // row pitch of the logits buffer (16-byte aligned rows for vector stores)
     st.logits.alloc((size_t)r_cap * st.logits_ld * 4);
@@ -463,6 +465,7 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.pending_src.clear();
     if (const char* e = getenv("WRS_DEC_BIG_GEMM_ROWS")) dec_big_gemm_rows = atoi(e);
     if (const char* e = getenv("WRS_DEC_PRING")) dec_slab_path = e[0] != '1';
+    if (const char* e = getenv("WRS_DEC_FUSED")) dec_fused_tiny = e[0] != '0';
     if (parity_f32) init_state_f32(st);
 }
 
@@ -548,6 +551,10 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
         decoder_step_big(st, rows, phys_mul, q_per_audio, update_anc, want_logits);
         return;
     }
+    if (rows <= 16 && dec_fused_tiny) {
+        decoder_step_tiny(st, rows, phys_mul, q_per_audio, update_anc, want_logits);
+        return;
+    }
     if (update_anc) {
         Timed tm(timer, "dec_anc_update", stream);
         launch_anc_update(st.anc.as<int>(), anc_stride, n_ctx, rows, sp, st.src_d(), stream);
@@ -612,6 +619,88 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
             const float* bb = (l + 1 < L_dec) ? dec[l + 1].attn_ln_b : ln_b;
             launch_finish_residual_ln(st.x.as<float>(), slab, ks_m2, mp, b.mlp2_b, g, bb, rows, D, st.xn.as<half_t>(), stream);
         }
+    }
+    if (want_logits) decoder_logits(st, rows);
+}
+
+// Decode step for <= 16 rows (one window x beam 5: the reference's own usage mode, TranscribeTask::run).  There the step is
+// launch-bound (12 dependent launches per layer), so the three "finish" kernels and the MLP-1 finish of a layer run inside
+// the NEXT GEMM's prologue (gemm_dec_fused: every workgroup rebuilds its activation fragments from the previous GEMM's
+// split-K slabs; 5 rows of L2-resident data): 8 launches per layer.  Slabs and the residual stream ping-pong between two
+// buffers (a fused GEMM reads one while writing the other).
+void Model::decoder_step_tiny(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits) {
+    const float scale = std::pow((float)(D / H), -0.25f);
+    const StepParams* sp = st.sp_d();
+    const int64_t anc_stride = (int64_t)st.r_cap * n_ctx;
+    const size_t kv_layer = (size_t)st.r_cap * n_ctx * D;
+    const size_t cross_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
+    const int n_audio = rows / q_per_audio;
+    const int mp = 16;
+    const int64_t np_d = round_up(D, 128), np_3d = round_up(3 * D, 128), np_4d = round_up(4 * (int64_t)D, 128);
+    float* slabs[2] = {st.slab.as<float>(), st.slab2.as<float>()};
+    float* xs[2] = {st.x.as<float>(), st.x2.as<float>()};
+    int sb = 0, xb = 0;  // buffer a GEMM writes next / buffer that holds the residual stream
+    half_t* att = st.att.as<half_t>();
+    if (update_anc) {
+        Timed tm(timer, "dec_anc_update", stream);
+        launch_anc_update(st.anc.as<int>(), anc_stride, n_ctx, rows, sp, st.src_d(), stream);
+    }
+    {
+        Timed tm(timer, "dec_embed_ln", stream);
+        launch_embed_ln(emb16, dec_pos, sp, st.tokens_d(), dec[0].attn_ln_g, dec[0].attn_ln_b, rows, D, xs[xb], st.xn.as<half_t>(), stream);
+    }
+    // pending producer: the previous GEMM's slabs + bias, not yet added to the residual stream
+    const float* pend_slab = nullptr;
+    const float* pend_bias = nullptr;
+    int pend_ks = 0;
+    auto plain = [&](const char* name, const half_t* a, const half_t* w, int64_t N, int64_t n_pad, int64_t K) -> int {
+        Timed tm(timer, name, stream);
+        launch_gemm_dec(a, w, rows, N, n_pad, K, slabs[sb], stream);
+        pend_slab = slabs[sb];
+        sb ^= 1;
+        return gemm_dec_plan(rows, N, K, nullptr, nullptr);
+    };
+    auto fused_ln = [&](const char* name, const float* g, const float* b, const half_t* w, int64_t N, int64_t n_pad) -> int {
+        Timed tm(timer, name, stream);
+        const int ks = launch_gemm_dec_fused(0, pend_slab, pend_ks, mp, pend_bias, xs[xb], xs[xb ^ 1], g, b, w, rows, N, n_pad, D, slabs[sb], stream);
+        xb ^= 1;
+        pend_slab = slabs[sb];
+        sb ^= 1;
+        return ks;
+    };
+    for (int l = 0; l < L_dec; ++l) {
+        const BlockW& b = dec[l];
+        int ks_qkv;
+        if (l == 0) ks_qkv = plain("dec_gemm_qkv", st.xn.as<half_t>(), b.qkv_w, 3 * D, np_3d, D);
+        else ks_qkv = fused_ln("dec_gemm_qkv", b.attn_ln_g, b.attn_ln_b, b.qkv_w, 3 * D, np_3d);  // + the previous layer's MLP-2 finish
+        {
+            Timed tm(timer, "dec_attn_self", stream);
+            launch_attn_self(pend_slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer,
+                             st.anc.as<int>(), anc_stride, n_ctx, rows, q_per_audio, phys_mul, H, D, sp, att, stream);
+        }
+        pend_ks = plain("dec_gemm_out", att, b.out_w, D, np_d, D);
+        pend_bias = b.out_b;
+        const int ks_cq = fused_ln("dec_gemm_cq", b.cross_ln_g, b.cross_ln_b, b.cq_w, D, np_d);
+        {
+            Timed tm(timer, "dec_attn_cross", stream, (double)n_audio * 2.0 * T * D * 2.0);
+            launch_attn_cross(pend_slab, ks_cq, mp, b.cq_b, scale, st.ckp(st.cross_sel) + l * cross_layer, st.cvp(st.cross_sel) + l * cross_layer,
+                              n_audio, q_per_audio, T, H, att, stream);
+        }
+        pend_ks = plain("dec_gemm_out", att, b.cout_w, D, np_d, D);
+        pend_bias = b.cout_b;
+        const int ks_m1 = fused_ln("dec_gemm_mlp1", b.mlp_ln_g, b.mlp_ln_b, b.mlp0_w, 4 * D, np_4d);
+        {   // MLP-2 with the MLP-1 finish (bias + exact GELU) in its prologue
+            Timed tm(timer, "dec_gemm_mlp2", stream);
+            pend_ks = launch_gemm_dec_fused(1, pend_slab, ks_m1, mp, b.mlp0_b, nullptr, nullptr, nullptr, nullptr, b.mlp2_w, rows, D, np_d,
+                                            4 * (int64_t)D, slabs[sb], stream);
+            pend_slab = slabs[sb];
+            sb ^= 1;
+            pend_bias = b.mlp2_b;
+        }
+    }
+    {   // the last MLP-2's finish + final LayerNorm (model.rs:518) stay a kernel: the logits GEMM takes packed activations
+        Timed tm(timer, "dec_finish_ln", stream);
+        launch_finish_residual_ln(xs[xb], pend_slab, pend_ks, mp, pend_bias, ln_g, ln_b, rows, D, st.xn.as<half_t>(), stream);
     }
     if (want_logits) decoder_logits(st, rows);
 }

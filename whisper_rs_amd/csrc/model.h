@@ -69,6 +69,7 @@ struct DecState {
     DevBuf kc, vc;              // [L][r_cap][n_ctx][D]
     DevBuf anc;                 // [2][r_cap][n_ctx]
     DevBuf x, xn, att, h, slab, logits, ckv_tmp;
+    DevBuf slab2, x2;           // <= 16-row path with fused producers (gemm_dec_fused): second slab and residual-stream buffers (ping-pong)
     DevBuf q16;                 // [act_rows, D] fp16 row-major: the step's query projection (self- and cross-attention), >= 480-row path
     std::unique_ptr<DecStateF32> f32;  // f32 parity mode only
     PrefillWorkspace prefill;   // allocated on first use
@@ -141,6 +142,7 @@ struct Model {
     StageTimer* timer = nullptr;            // optional per-kernel timing sink
     int debug_enc_stop = 0;                 // debug: stop the encoder after N launches
     int dec_big_gemm_rows = 480;            // decode steps with at least this many rows use the tiled GEMM (env WRS_DEC_BIG_GEMM_ROWS)
+    bool dec_fused_tiny = true;             // <= 16 rows: finish kernels fused into the next GEMM's prologue (WRS_DEC_FUSED=0: off)
     bool dec_slab_path = true;              // split-K fp32 slabs + finish kernels; WRS_DEC_PRING=1 selects the persistent-ring form (slower, see model.cpp)
     // live timing of the dominant decode kernel (cross-attention) with HIP events on this stream: every
     // `cross_ev_every`-th decode step is launched eagerly (not from the graph) with event pairs around the
@@ -178,6 +180,7 @@ struct Model {
     // q_per_audio = rows sharing one audio's cross K/V.  Step scalars / tokens / src must already be in st.sp_dev.
     void decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits);
     void decoder_step_big(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits);
+    void decoder_step_tiny(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits);  // <= 16 rows
     // tied output projection of st.xn (packed activations, `rows` rows) into st.logits (model.rs:521)
     void decoder_logits(DecState& st, int rows);
     // The decoder's first forward pass: all S prompt tokens of every audio at once (reference decode/mod.rs:236-245,
