@@ -203,7 +203,8 @@ pub struct DecodeOptions {
     pub prompt: Option<Vec<i64>>,
 }
 
-/// reference `DecodeOutput` (decode/mod.rs:109-119); `audio_features` stays on the device (pointer valid until the next run)
+/// reference `DecodeOutput` (decode/mod.rs:109-119); `audio_features` stays on the device (pointer valid until the model's
+/// next encoder pass; `DecodeTask::audio_features` copies it out)
 #[derive(Debug, Clone)]
 pub struct DecodeOutput {
     pub audio_features_device: *const f32,
@@ -290,6 +291,13 @@ impl<'a> DecodeTask<'a> {
         unsafe { ffi::wrs_decode_result_free(&mut r) };
         let _ = &self.tokenizer;
         Ok(outs)
+    }
+    /// host copy of `DecodeOutput.audio_features` (decode/mod.rs:110) of window `index` of the batch decoded last:
+    /// [n_audio_ctxs * n_audio_states] f32.  Fails once the model has run its encoder again.
+    pub fn audio_features(&mut self, index: usize, dims: &ModelDims) -> anyhow::Result<Vec<f32>> {
+        let mut out = vec![0f32; (dims.n_audio_ctxs * dims.n_audio_states) as usize];
+        check(unsafe { ffi::wrs_decode_task_read_audio_features(self.handle, index as i32, out.as_mut_ptr(), out.len() as i64) })?;
+        Ok(out)
     }
 }
 impl Drop for DecodeTask<'_> {

@@ -212,7 +212,11 @@ typedef struct wrs_decode_output {
     double avg_logprob;
     double no_speech_prob;
     double sum_logprob;
-    const float* audio_features_device; /* device pointer [n_audio_ctxs, n_audio_states] fp32, valid until the next run */
+    const float* audio_features_device; /* `DecodeOutput.audio_features` (decode/mod.rs:110): DEVICE pointer
+                                         * [n_audio_ctxs, n_audio_states] fp32 into the model's encoder workspace, valid until
+                                         * the next encoder pass on this model; NULL when a later batch was already queued with
+                                         * wrs_decode_task_encode_async (overlapped mode / window pool).  Host copy:
+                                         * wrs_decode_task_read_audio_features */
     char* text; /* `DecodeOutput.text` = tokenizer.decode(tokens) (decode/mod.rs:404): library-owned UTF-8, NULL unless a
                  * tokenizer is attached with wrs_decode_task_set_tokenizer */
 } wrs_decode_output;
@@ -240,6 +244,10 @@ int wrs_decode_task_run(wrs_decode_task* t, const float* mel, int32_t n_audio, i
 /* same, starting from encoder output [n_audio, n_audio_ctxs, n_state] f32 (run_inner after :296) */
 int wrs_decode_task_run_features(wrs_decode_task* t, const float* audio_features, int32_t n_audio, int mem_kind,
                                  wrs_decode_result* result);
+/* host copy of `DecodeOutput.audio_features` (decode/mod.rs:110,399) of window `audio_index` of the batch the task decoded
+ * last: out[n_audio_ctxs * n_audio_states] f32, n_floats must be exactly that.  WRS_EINVAL once the encoder workspace has
+ * been reused (another run, or wrs_decode_task_encode_async of a later batch). */
+int wrs_decode_task_read_audio_features(wrs_decode_task* t, int32_t audio_index, float* out, int64_t n_floats);
 /* same, starting from raw audio windows [n_audio, 480000] f32: log-mel + run.  EVERY WINDOW IS ITS OWN RECORDING here: the
  * log-mel floor (max - 8, audio.rs:256) uses the window's own maximum.  The reference's long-form loop normalises over the
  * whole file instead (transcribe.rs:111-112): wrs_transcribe_task_run / _run_chunked do that; this entry, encode_async and

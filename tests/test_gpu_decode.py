@@ -136,6 +136,36 @@ def test_run_audio_matches_run_mel(gpu):
     task.close()
 
 
+def test_audio_features_copy_out(gpu):
+    """`DecodeOutput.audio_features` (decode/mod.rs:110,399): the encoder output of every window of the decoded batch can be
+    copied to the host and equals AudioEncoder::forward of the same spectrogram; once the encoder workspace belongs to a
+    later batch (another run, or a batch queued with encode_async) the device pointer is NULL and the copy is refused."""
+    from whisper_rs_amd import synth
+    d = MODEL_DIMS["nano"]
+    gm = gpu_model(gpu, "nano")
+    mel = mel_windows(2)
+    task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=4, max_audio=2))
+    outs = task.run(mel)
+    assert all(o.audio_features_device for o in outs)
+    got = np.stack([task.read_audio_features(i, d.n_audio_ctxs, d.n_audio_states) for i in range(2)])
+    with pytest.raises(gpu.WrsError):
+        task.read_audio_features(2, d.n_audio_ctxs, d.n_audio_states)
+    np.testing.assert_array_equal(got, gm.encoder_forward(mel))
+    with pytest.raises(gpu.WrsError):  # encoder_forward above re-used the workspace (same values, but not this batch's any more)
+        task.read_audio_features(0, d.n_audio_ctxs, d.n_audio_states)
+    a = synth.make_audio(2, seed=77)
+    task.encode_async(a)
+    task.encode_async(a)
+    stale = task.run_pending()  # the second batch's encoder owns the workspace
+    assert all(not o.audio_features_device for o in stale)
+    with pytest.raises(gpu.WrsError):
+        task.read_audio_features(0, d.n_audio_ctxs, d.n_audio_states)
+    live = task.run_pending()
+    assert all(o.audio_features_device for o in live)
+    assert np.isfinite(task.read_audio_features(1, d.n_audio_ctxs, d.n_audio_states)).all()
+    task.close()
+
+
 def test_capacity_and_errors(gpu):
     gm = gpu_model(gpu, "nano")
     task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=4, max_audio=1))

@@ -53,8 +53,12 @@ def test_wide_decode_480_rows_teacher_forced(gpu, monkeypatch, pring):
     print(f"wide, {n * 5} rows: {exact}/{steps} selections reproduced exactly")
 
 
-def test_wide_decode_small_batch_teacher_forced(gpu):
-    """3 audios x beam 5 = 15 rows at the same width: the latency-optimised split-K path (gemm_dec / skinny logits)."""
+@pytest.mark.parametrize("fused", [False, True], ids=["finish_kernels", "fused_prologue"])
+def test_wide_decode_small_batch_teacher_forced(gpu, monkeypatch, fused):
+    """3 audios x beam 5 = 15 rows at the same width: the latency-optimised split-K path (gemm_dec / skinny logits), and
+    its opt-in variant with the finish kernels folded into the next GEMM's prologue (WRS_DEC_FUSED=1, gemm_dec_fused)."""
+    if fused:
+        monkeypatch.setenv("WRS_DEC_FUSED", "1")  # read when a decoder state is created
     exact, steps = _teacher_forced_check(gpu, "wide", 3, 24, WIDE_MIN_EXACT, feats=_features(3, 8), ids=TokenIds.multilingual(), cand_tol=WIDE_CAND_TOL)
     print(f"wide, 15 rows: {exact}/{steps} selections reproduced exactly")
 

@@ -110,6 +110,7 @@ SYMBOLS = {
     "wrs_decode_task_set_prompt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "wrs_decode_task_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, P(DecodeResultC)]),
     "wrs_decode_task_run_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, P(DecodeResultC)]),
+    "wrs_decode_task_read_audio_features": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "wrs_decode_task_run_audio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, P(DecodeResultC)]),
     "wrs_decode_task_encode_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int]),
     "wrs_decode_task_run_pending": (C.c_int, [C.c_void_p, P(DecodeResultC)]),

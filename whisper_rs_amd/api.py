@@ -387,6 +387,12 @@ class DecodeTask:
         L.check(self._lib.wrs_decode_task_run_audio(self._h, _ptr(a), a.shape[0], L.WRS_MEM_HOST, C.byref(res)))
         return self._collect(res)
 
+    def read_audio_features(self, audio_index: int, n_ctx: int, n_state: int) -> np.ndarray:
+        """host copy of `DecodeOutput.audio_features` (decode/mod.rs:110) of one window of the last decoded batch"""
+        out = np.empty((n_ctx, n_state), np.float32)
+        L.check(self._lib.wrs_decode_task_read_audio_features(self._h, audio_index, _ptr(out), out.size))
+        return out
+
     def encode_async(self, audio_, n_audio: Optional[int] = None):
         """queue mel + encoder + cross-K/V of a window batch on the side stream (overlapped mode).  audio_: numpy
         [n, 480000] (host) or a device pointer (int) with n_audio given; a device buffer must outlive the batch."""

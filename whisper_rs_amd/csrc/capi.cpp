@@ -105,6 +105,7 @@ int wrs_decoder_forward(wrs_model* h, const int64_t* tokens, int n_batch, int n_
         if (xa) {  // Cached::forward recomputes Linear(xa) on every call (model.rs:79)
             const size_t n = (size_t)n_batch * m.T * m.D;
             m.ensure_encoder_ws(n_batch);
+            ++m.enc_ws.epoch;
             HIP_CHECK(hipMemcpyAsync(m.enc_ws.xa32.p, xa, n * 4, hipMemcpyHostToDevice, m.stream));
             launch_f32_to_f16(m.enc_ws.xa32.as<float>(), m.enc_ws.xa16.as<half_t>(), (int64_t)n, m.stream);
             m.load_cross_kv(st, m.enc_ws.xa16.as<half_t>(), n_batch);
@@ -261,7 +262,21 @@ int wrs_decode_task_run_features(wrs_decode_task* t, const float* feats, int32_t
         HIP_CHECK(hipMemcpyAsync(m.enc_ws.xa32.p, feats, n * 4, mem_kind == WRS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m.stream));
         launch_f32_to_f16(m.enc_ws.xa32.as<float>(), m.enc_ws.xa16.as<half_t>(), (int64_t)n, m.stream);
         m.enc_ws.n_encoded = n_audio;
+        ++m.enc_ws.epoch;
         t->t.run_encoded(n_audio, result);
+    });
+}
+int wrs_decode_task_read_audio_features(wrs_decode_task* t, int32_t audio_index, float* out, int64_t n_floats) {
+    return guarded([&] {
+        WRS_REQUIRE(t && out, "wrs_decode_task_read_audio_features: null argument");
+        Model& m = *t->t.m;
+        WRS_REQUIRE(audio_index >= 0 && audio_index < t->t.features_n && t->t.features_epoch == m.enc_ws.epoch,
+                    "wrs_decode_task_read_audio_features: window %d is not in the encoder workspace any more (%d windows of the last decode are)",
+                    audio_index, t->t.features_n);
+        WRS_REQUIRE(n_floats == (int64_t)m.T * m.D, "wrs_decode_task_read_audio_features: %ld floats, the features are [%d, %d]", (long)n_floats, m.T, m.D);
+        m.use();
+        HIP_CHECK(hipMemcpyAsync(out, m.enc_ws.xa32.as<float>() + (size_t)audio_index * m.T * m.D, (size_t)n_floats * 4, hipMemcpyDeviceToHost, m.stream));
+        HIP_CHECK(hipStreamSynchronize(m.stream));
     });
 }
 int wrs_decode_task_run_audio(wrs_decode_task* t, const float* audio, int32_t n_audio, int mem_kind, wrs_decode_result* result) {

@@ -217,6 +217,7 @@ int wrs_debug_decode_forced_features(wrs_decode_task* t, const float* feats, int
         launch_f32_to_f16(m.enc_ws.xa32.as<float>(), m.enc_ws.xa16.as<half_t>(), (int64_t)n, m.stream);
         HIP_CHECK(hipStreamSynchronize(m.stream));
         m.enc_ws.n_encoded = n_audio;
+        ++m.enc_ws.epoch;
         t->t.run_forced(n_audio, n_steps, ftok, fsrc, out_lp, out_id, out_no_speech, true);
     });
 }

@@ -43,6 +43,7 @@ void DecodeTask::encode_async(const float* audio, int n_audio, int mem_kind, boo
     WRS_REQUIRE(pending.size() < 2, "encode_async: two batches are already queued (call run_pending first)");
     WRS_REQUIRE(!m->parity_f32, "encode_async: the f32 parity mode has no overlapped path");
     m->use();
+    features_n = 0;  // the encoder workspace is about to be overwritten
     if (!side) {
         int prio_least = 0, prio_greatest = 0;
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
@@ -666,6 +667,8 @@ void DecodeTask::run_forced(int n_audio, int n_steps, const int32_t* ftok, const
 // finalize (beam_search.rs:151-206 / greedy.rs:54-58), slice [sample_begin, first EOT) (decode/mod.rs:356-370),
 // MaximumLikelihoodRanker::rank (max_likelihood.rs:13-34), avg_logprob (decode/mod.rs:389-397).
 void DecodeTask::finalize(int n_audio, wrs_decode_result* out) {
+    features_n = (m && pending.empty()) ? n_audio : 0;
+    features_epoch = m ? m->enc_ws.epoch : 0;
     const int G = group;
     std::vector<std::vector<FinishedSeq>> cands(n_audio);
     for (int i = 0; i < n_audio; ++i) {
@@ -727,7 +730,8 @@ void DecodeTask::finalize(int n_audio, wrs_decode_result* out) {
         o.sum_logprob = cands[i][best].score;
         o.avg_logprob = cands[i][best].score / ((double)o.n_tokens + 1.0);
         o.no_speech_prob = no_speech[i];
-        o.audio_features_device = m ? m->enc_ws.xa32.as<float>() + (size_t)i * m->T * m->D : nullptr;
+        // overlapped mode: a batch encoded after this one already owns the encoder workspace, its features are gone
+        o.audio_features_device = (m && pending.empty()) ? m->enc_ws.xa32.as<float>() + (size_t)i * m->T * m->D : nullptr;
         o.text = tokenizer ? dup_cstr(tokenizer->decode(o.tokens, o.n_tokens)) : nullptr;  // decode/mod.rs:404
     }
 }

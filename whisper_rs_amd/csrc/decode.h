@@ -115,6 +115,8 @@ struct DecodeTask {
     void simulate(const wrs_token_ids& tid, const wrs_decode_options& o, const int64_t* initial, int n_initial, int n_audio, int n_steps,
                   const float* lp, const int32_t* id, wrs_decode_result* out);
     void finalize(int n_audio, wrs_decode_result* out);
+    uint64_t features_epoch = 0;
+    int features_n = 0;  // windows of the last decoded batch whose encoder output still sits in m->enc_ws.xa32 (0: overwritten)
     void record_trace(int R);
 };
 

@@ -1035,11 +1035,14 @@ struct DecFusedParams {
     const float* ln_b;
 };
 
+static constexpr int DECF_SLAB_CHUNK = 4;  // producer slabs read per round trip
+
 template <int KPS, int MODE>
 __global__ __launch_bounds__(256) void gemm_dec_fused_kernel(const DecFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char decf_smem[];
     half8* wlds = reinterpret_cast<half8*>(decf_smem);            // [4 waves * KPS][64]
     half8* alds = wlds + (size_t)4 * KPS * 64;                     // [KPS][64]
+    float* rowbuf = reinterpret_cast<float*>(alds + (size_t)KPS * 64);  // DECF_LN: the producer's rows [M][K] fp32
     __shared__ float stat_mean[16], stat_rstd[16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int ntile = blockIdx.x * 4 + wave;
@@ -1054,21 +1057,41 @@ __global__ __launch_bounds__(256) void gemm_dec_fused_kernel(const DecFusedParam
                                          (__attribute__((address_space(3))) void*)(wlds + (size_t)(wave * KPS + i) * 64), 16, 0, DEC_W_AUX);
 
     // value of the producer's output at (row m, columns k .. k+3)
+    // (slabs are read four at a time with independent loads: one dependent L2-miss round trip per slab made this prologue 14 us)
     auto produced4 = [&](int m, int k) -> floatx4 {
-        floatx4 a = *reinterpret_cast<const floatx4*>(p.slab_in + (int64_t)m * K + k);
-        for (int sidx = 1; sidx < p.ksplit_in; ++sidx) a += *reinterpret_cast<const floatx4*>(p.slab_in + ((int64_t)sidx * p.m_pad_in + m) * K + k);
-        a += *reinterpret_cast<const floatx4*>(p.bias_in + k);
-        if (MODE == DECF_LN) a += *reinterpret_cast<const floatx4*>(p.x_in + (int64_t)m * K + k);
+        const floatx4 bi = *reinterpret_cast<const floatx4*>(p.bias_in + k);
+        floatx4 xr = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (MODE == DECF_LN) xr = *reinterpret_cast<const floatx4*>(p.x_in + (int64_t)m * K + k);
+        floatx4 a = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < p.ksplit_in; s0 += DECF_SLAB_CHUNK) {
+            floatx4 v[DECF_SLAB_CHUNK];
+#pragma unroll
+            for (int j = 0; j < DECF_SLAB_CHUNK; ++j)
+                v[j] = s0 + j < p.ksplit_in ? *reinterpret_cast<const floatx4*>(p.slab_in + ((int64_t)(s0 + j) * p.m_pad_in + m) * K + k) : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < DECF_SLAB_CHUNK; ++j) a += v[j];
+        }
+        a += bi;
+        if (MODE == DECF_LN) a += xr;
         return a;
     };
     if (MODE == DECF_LN) {
-        // full-row LayerNorm statistics (eps 1e-5, two passes like layernorm_kernel): 16 threads per row
+        // the producer's M full rows -> LDS, all 256 threads, every load independent (one memory round trip), then the
+        // LayerNorm statistics (eps 1e-5, two passes like layernorm_kernel) from LDS: 16 threads per row
+        const int kq = K >> 2;
+#pragma unroll 2
+        for (int i = tid; i < p.M * kq; i += 256) {
+            const int m = i / kq, k = (i - m * kq) * 4;
+            *reinterpret_cast<floatx4*>(rowbuf + (size_t)m * K + k) = produced4(m, k);
+        }
+        __syncthreads();
         const int r = tid >> 4, sub = tid & 15;
         float mean = 0.f, rstd = 0.f;
         if (r < p.M) {
+            const float* row = rowbuf + (size_t)r * K;
             float sacc = 0.f;
             for (int k = sub * 4; k < K; k += 64) {
-                const floatx4 a = produced4(r, k);
+                const floatx4 a = *reinterpret_cast<const floatx4*>(row + k);
                 sacc += (a[0] + a[1]) + (a[2] + a[3]);
             }
 #pragma unroll
@@ -1076,7 +1099,7 @@ __global__ __launch_bounds__(256) void gemm_dec_fused_kernel(const DecFusedParam
             mean = sacc / (float)K;
             float q = 0.f;
             for (int k = sub * 4; k < K; k += 64) {
-                const floatx4 a = produced4(r, k);
+                const floatx4 a = *reinterpret_cast<const floatx4*>(row + k);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float d = a[e] - mean;
@@ -1095,7 +1118,14 @@ __global__ __launch_bounds__(256) void gemm_dec_fused_kernel(const DecFusedParam
         const int m = lane & 15, k0 = (ks0 + kk) * 32 + 8 * (lane >> 4);
         half8 h = {0, 0, 0, 0, 0, 0, 0, 0};
         if (m < p.M) {
-            const floatx4 a0 = produced4(m, k0), a1 = produced4(m, k0 + 4);
+            floatx4 a0, a1;
+            if (MODE == DECF_LN) {
+                a0 = *reinterpret_cast<const floatx4*>(rowbuf + (size_t)m * K + k0);
+                a1 = *reinterpret_cast<const floatx4*>(rowbuf + (size_t)m * K + k0 + 4);
+            } else {
+                a0 = produced4(m, k0);
+                a1 = produced4(m, k0 + 4);
+            }
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             if (MODE == DECF_LN) {
                 if (blockIdx.x == 0) {  // one workgroup per k-slice publishes the new residual stream
@@ -1136,9 +1166,19 @@ __global__ __launch_bounds__(256) void gemm_dec_fused_kernel(const DecFusedParam
 
 template <int KPS, int MODE>
 static void launch_decf(const DecFusedParams& p, int n_pad, hipStream_t s) {
-    const size_t shmem = (size_t)(1 + 4) * KPS * 1024;
+    const size_t shmem = (size_t)(1 + 4) * KPS * 1024 + (MODE == DECF_LN ? (size_t)p.M * p.ksteps * 32 * 4 : 0);
+    WRS_REQUIRE(shmem <= 159 * 1024, "gemm_dec_fused: %zu bytes of LDS (rows %d, K %d)", shmem, p.M, p.ksteps * 32);
     static std::atomic<bool> attr_set[64];
-    allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_dec_fused_kernel<KPS, MODE>), shmem, attr_set);
+    static std::atomic<size_t> attr_max[64];
+    {   // the limit must cover the largest request seen on this device (rows vary between calls)
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && attr_max[dev].load() < shmem) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dec_fused_kernel<KPS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            attr_max[dev].store(shmem);
+            attr_set[dev].store(true);
+        }
+    }
     dim3 grid((unsigned)(n_pad / 64), (unsigned)(p.ksteps / KPS));
     gemm_dec_fused_kernel<KPS, MODE><<<grid, 256, shmem, s>>>(p);
 }

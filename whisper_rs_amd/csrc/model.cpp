@@ -345,6 +345,7 @@ void Model::encoder_from_mel_t(int n) {
     WRS_REQUIRE(n >= 1 && n <= enc_ws.cap, "encoder: bad window count %d", n);
     EncoderWorkspace& w = enc_ws;
     w.n_encoded = n;
+    ++w.epoch;
     const int64_t M = (int64_t)n * T;
     const float scale = std::pow((float)(D / H), -0.25f);
     const double dM = (double)M, dD = (double)D;
@@ -464,8 +465,12 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.n_audio = 0;
     st.pending_src.clear();
     if (const char* e = getenv("WRS_DEC_BIG_GEMM_ROWS")) dec_big_gemm_rows = atoi(e);
-    if (const char* e = getenv("WRS_DEC_PRING")) dec_slab_path = e[0] != '1';
-    if (const char* e = getenv("WRS_DEC_FUSED")) dec_fused_tiny = e[0] != '0';
+    {   // experiment switches, re-read for every decoder state (unset = the default path)
+        const char* e = getenv("WRS_DEC_PRING");
+        dec_slab_path = !(e && e[0] == '1');
+        e = getenv("WRS_DEC_FUSED");
+        dec_fused_tiny = e && e[0] == '1';
+    }
     if (parity_f32) init_state_f32(st);
 }
 

@@ -44,6 +44,7 @@ struct DecStateF32 {
 struct EncoderWorkspace {
     int cap = 0;  // windows
     int n_encoded = 0;  // windows whose encoder output currently sits in xa16/xa32
+    uint64_t epoch = 0;  // bumped by every write of xa16/xa32 (a DecodeTask remembers the epoch its outputs' features belong to)
     DevBuf mel_t, c1, x, xn, qkv, kp, vp, att, h, xa16, xa32;
 };
 
@@ -142,7 +143,7 @@ struct Model {
     StageTimer* timer = nullptr;            // optional per-kernel timing sink
     int debug_enc_stop = 0;                 // debug: stop the encoder after N launches
     int dec_big_gemm_rows = 480;            // decode steps with at least this many rows use the tiled GEMM (env WRS_DEC_BIG_GEMM_ROWS)
-    bool dec_fused_tiny = true;             // <= 16 rows: finish kernels fused into the next GEMM's prologue (WRS_DEC_FUSED=0: off)
+    bool dec_fused_tiny = false;            // <= 16 rows, WRS_DEC_FUSED=1: finish kernels fused into the next GEMM's prologue (8 launches per layer instead of 12, but slower: DESIGN.md section 4)
     bool dec_slab_path = true;              // split-K fp32 slabs + finish kernels; WRS_DEC_PRING=1 selects the persistent-ring form (slower, see model.cpp)
     // live timing of the dominant decode kernel (cross-attention) with HIP events on this stream: every
     // `cross_ev_every`-th decode step is launched eagerly (not from the graph) with event pairs around the

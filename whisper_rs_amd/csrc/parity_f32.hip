@@ -234,6 +234,7 @@ void Model::encoder_f32(int n) {
     WRS_REQUIRE(n >= 1 && n <= enc_ws32.cap && n <= enc_ws.cap, "encoder: bad window count %d", n);
     EncoderWorkspaceF32& w = enc_ws32;
     enc_ws.n_encoded = n;
+    ++enc_ws.epoch;
     const int64_t M = (int64_t)n * T;
     const float scale = std::pow((float)(D / H), -0.25f);
     float* x = enc_ws.x.as<float>();
