@@ -222,12 +222,33 @@ void DecodeTask::upload_step(int) {
     HIP_CHECK(hipMemcpyAsync(st.sp_dev.p, st.sp_host.p, st.sp_bytes(), hipMemcpyHostToDevice, m->stream));
 }
 
-static int ts_mode_of(const std::vector<int64_t>& row, int sample_begin, int tsb) {
+static int ts_mode_of(const SeqStore& seqs, int row, int sample_begin, int tsb) {
     // timestamp_tokens.rs:47-66
-    const int n = (int)row.size() - sample_begin;
-    const bool last = n >= 1 && row[row.size() - 1] >= tsb;
-    const bool second = n < 2 || row[row.size() - 2] >= tsb;
+    const int n = seqs.len(row) - sample_begin;
+    const bool last = n >= 1 && seqs.back(row) >= tsb;
+    const bool second = n < 2 || seqs.back(seqs.parent(row)) >= tsb;
     return last ? (second ? 1 : 2) : 0;
+}
+
+void DecodeTask::init_rows(int n_audio) {
+    const int G = group, R = n_audio * G;
+    seqs.clear();
+    seqs.reserve((size_t)n_audio * initial_tokens.size() + (size_t)(R + n_audio) * (size_t)(std::max(sample_len, 1) + 1));
+    rows.resize(R);
+    std::vector<int64_t> prompt;
+    int shared = -1;
+    for (int a = 0; a < n_audio; ++a) {
+        int root;
+        if (audio_lang.empty()) {
+            if (shared < 0) shared = seqs.chain(initial_tokens);
+            root = shared;
+        } else {
+            prompt = initial_tokens;
+            prompt[sot_idx + 1] = audio_lang[a];
+            root = seqs.chain(prompt);
+        }
+        for (int j = 0; j < G; ++j) rows[a * G + j] = root;
+    }
 }
 
 void DecodeTask::step_decode(int R) {
@@ -285,13 +306,12 @@ void DecodeTask::record_candidates(int R, bool step0) {
 }
 
 // test aid: replace the outcome of step `step` by the given decisions (the finished lists keep what update_* admitted)
-void DecodeTask::apply_forced(int step, const std::vector<std::vector<int64_t>>& old_rows) {
+void DecodeTask::apply_forced(int step, const std::vector<int>& old_rows) {
     const int R = (int)old_rows.size();
     for (int r = 0; r < R; ++r) {
         const int src = forced_src[(size_t)step * R + r];
         WRS_REQUIRE(src >= 0 && src < R, "forced decode: source %d out of range", src);
-        rows[r] = old_rows[src];
-        rows[r].push_back(forced_tok[(size_t)step * R + r]);
+        rows[r] = seqs.append(old_rows[src], forced_tok[(size_t)step * R + r]);
         sources[r] = src;
         sum_logprobs[r] = forced_slp[(size_t)step * R + r];
     }
@@ -299,7 +319,7 @@ void DecodeTask::apply_forced(int step, const std::vector<std::vector<int64_t>>&
 
 void DecodeTask::record_trace(int R) {
     for (int r = 0; r < R; ++r) {
-        tr_tokens.push_back((int32_t)rows[r].back());
+        tr_tokens.push_back((int32_t)seqs.back(rows[r]));
         tr_src.push_back(sources[r]);
         tr_slp.push_back(sum_logprobs[r]);
     }
@@ -310,8 +330,8 @@ void DecodeTask::record_trace(int R) {
 bool DecodeTask::update_beam(int n_audio, bool step0, const float* lp, const int* id) {
     const int G = group, k = G + 1;
     struct Cand { int beam; int64_t token; double score; int source; };
-    // scratch rows keep their capacity from step to step (1280 rows x 224 steps: no allocation on the step path)
-    std::vector<std::vector<int64_t>>& new_rows = scratch_rows;
+    // a step appends one node per row to the prefix tree (no sequence is copied, nothing is allocated on the step path)
+    std::vector<int>& new_rows = scratch_rows;
     new_rows.resize((size_t)n_audio * G);
     std::vector<float>& new_slp = scratch_slp;
     std::vector<int>& new_src = scratch_src;
@@ -332,7 +352,7 @@ bool DecodeTask::update_beam(int n_audio, bool step0, const float* lp, const int
                 const double score = (double)sum_logprobs[idx] + (double)lp[trow * k + c];  // :71
                 bool dup = false;
                 for (auto& e : cands) {
-                    if (e.token == tok && (e.beam == j || rows[i * G + e.beam] == rows[idx])) {
+                    if (e.token == tok && (e.beam == j || seqs.equal(rows[i * G + e.beam], rows[idx]))) {
                         e.score = score;  // HashMap insert overwrites the value, key position unchanged (:77)
                         e.source = idx;
                         dup = true;
@@ -342,21 +362,25 @@ bool DecodeTask::update_beam(int n_audio, bool step0, const float* lp, const int
                 if (!dup) cands.push_back({j, tok, score, idx});
             }
         }
-        std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.score > b.score; });  // :86
+        // :86 stable descending sort (at most G * (G + 1) candidates: insertion sort, no temporary buffer)
+        for (size_t a = 1; a < cands.size(); ++a) {
+            const Cand c = cands[a];
+            size_t b = a;
+            for (; b > 0 && cands[b - 1].score < c.score; --b) cands[b] = cands[b - 1];
+            cands[b] = c;
+        }
         std::vector<FinishedSeq> newly;
         int saved = 0;
         for (const auto& c : cands) {  // :87-104
             if (c.token == ids.eot) {
                 FinishedSeq f;
-                f.tokens = rows[i * G + c.beam];
+                seqs.materialize(rows[i * G + c.beam], f.tokens);
                 f.tokens.push_back(c.token);
                 f.score = c.score;
                 newly.push_back(std::move(f));
             } else {
                 const int dst = i * G + saved;
-                const std::vector<int64_t>& from = rows[i * G + c.beam];
-                new_rows[dst].assign(from.begin(), from.end());  // no allocation: capacity n_ctx + 2 reserved in run_decode
-                new_rows[dst].push_back(c.token);
+                new_rows[dst] = seqs.append(rows[i * G + c.beam], c.token);
                 new_slp[dst] = (float)c.score;  // :91-95 stored into the f32 tensor
                 new_src[dst] = c.source;
                 if (++saved == G) break;
@@ -389,10 +413,10 @@ bool DecodeTask::update_greedy(int n_audio, bool step0, const float* lp, const i
         const int trow = step0 ? r / G : r;
         int64_t tok = id[trow];
         WRS_REQUIRE(tok >= 0, "greedy: no finite logit in row %d", r);
-        const bool last_eot = rows[r].back() == ids.eot;
+        const bool last_eot = seqs.back(rows[r]) == ids.eot;
         if (!last_eot) sum_logprobs[r] = sum_logprobs[r] + lp[trow];  // :38 (f32 add)
         else tok = ids.eot;                                           // :40-44
-        rows[r].push_back(tok);
+        rows[r] = seqs.append(rows[r], tok);
         sources[r] = r;
         if (tok != ids.eot) completed = false;
     }
@@ -492,14 +516,10 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
     double tA = now_ms();
 
     // host state (decode/mod.rs:297-325)
-    rows.assign(R, initial_tokens);
+    if (!audio_lang.empty()) WRS_REQUIRE((int)audio_lang.size() >= n_audio, "run: %d windows but only %d languages set", n_audio, (int)audio_lang.size());
+    init_rows(n_audio);
     scratch_rows.resize(R);
-    for (int r = 0; r < R; ++r) { rows[r].reserve((size_t)m->n_ctx + 2); scratch_rows[r].reserve((size_t)m->n_ctx + 2); }
     tr_tokens.reserve((size_t)R * sample_len); tr_src.reserve((size_t)R * sample_len); tr_slp.reserve((size_t)R * sample_len);
-    if (!audio_lang.empty()) {
-        WRS_REQUIRE((int)audio_lang.size() >= n_audio, "run: %d windows but only %d languages set", n_audio, (int)audio_lang.size());
-        for (int r = 0; r < R; ++r) rows[r][sot_idx + 1] = audio_lang[r / G];
-    }
     sum_logprobs.assign(R, 0.f);
     sources.assign(R, 0);
     finished.assign(n_audio, {});
@@ -520,7 +540,7 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
 
     tA = now_ms();
     record_candidates(R, true);
-    std::vector<std::vector<int64_t>> old_rows;
+    std::vector<int> old_rows;
     if (forced_n > 0) old_rows = rows;
     bool completed = (mode == WRS_EXTRACT_BEAM_SEARCH) ? update_beam(n_audio, true, st.topk_lp(), st.topk_id()) : update_greedy(n_audio, true, st.topk_lp(), st.topk_id());
     if (forced_n > 0) apply_forced(0, old_rows);
@@ -529,7 +549,7 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
     t_host_ms += now_ms() - tA;
 
     for (int i = 1; i < sample_len; ++i) {  // decode/mod.rs:234-277
-        if (completed || (int)rows[0].size() > m->n_ctx) break;
+        if (completed || seqs.len(rows[0]) > m->n_ctx) break;
         tA = now_ms();
         StepParams* sp = st.sp_h();
         sp->cache_pos = S + i - 1;
@@ -537,9 +557,9 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
         WRS_REQUIRE(sp->pos_idx < m->n_ctx && sp->cache_pos < m->n_ctx, "decode: position %d out of range", sp->cache_pos);
         sp->parity = i & 1; sp->first_step = 0; sp->want_no_speech = 0; sp->n_rows = R;
         for (int r = 0; r < R; ++r) {
-            st.tokens_h()[r] = (int)rows[r].back();
+            st.tokens_h()[r] = (int)seqs.back(rows[r]);
             st.src_h()[r] = sources[r];
-            st.tsmode_h()[r] = timestamps ? ts_mode_of(rows[r], S, ids.ts_begin) : 0;
+            st.tsmode_h()[r] = timestamps ? ts_mode_of(seqs, rows[r], S, ids.ts_begin) : 0;
         }
         const double t1 = now_ms();
         step_decode(R);
@@ -577,7 +597,9 @@ void DecodeTask::simulate(const wrs_token_ids& tid, const wrs_decode_options& o,
     sample_begin = n_initial;
     const int G = group, R = n_audio * G, k = (mode == WRS_EXTRACT_BEAM_SEARCH) ? G + 1 : 1;
     memset(out, 0, sizeof(*out));
-    rows.assign(R, initial_tokens);
+    audio_lang.clear();
+    sample_len = std::max(1, n_steps);
+    init_rows(n_audio);
     sum_logprobs.assign(R, 0.f);
     sources.assign(R, 0);
     finished.assign(n_audio, {});
@@ -621,7 +643,12 @@ void DecodeTask::run_forced(int n_audio, int n_steps, const int32_t* ftok, const
     m->load_cross_kv(st, m->enc_ws.xa16.as<half_t>(), n_audio);
     launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m->n_ctx, m->n_ctx, st.r_cap, G, s);
     const FilterCfg cfg = filter_cfg();
-    rows.assign(R, initial_tokens);
+    {
+        const int keep = sample_len;
+        sample_len = std::max(sample_len, n_steps);  // node reservation of init_rows
+        init_rows(n_audio);
+        sample_len = keep;
+    }
     {
         std::vector<double> ns(n_audio, NAN);
         prefill(n_audio, ns.data());
@@ -634,12 +661,11 @@ void DecodeTask::run_forced(int n_audio, int n_steps, const int32_t* ftok, const
             out_id[(size_t)r * k + c] = st.topk_id()[(r / G) * k + c];
         }
     auto apply = [&](int step) {
-        std::vector<std::vector<int64_t>> nr(R);
+        std::vector<int> nr(R);
         for (int r = 0; r < R; ++r) {
             const int src = fsrc[(size_t)step * R + r];
             WRS_REQUIRE(src >= 0 && src < R, "run_forced: source %d out of range", src);
-            nr[r] = rows[src];
-            nr[r].push_back(ftok[(size_t)step * R + r]);
+            nr[r] = seqs.append(rows[src], ftok[(size_t)step * R + r]);
         }
         rows.swap(nr);
         sources.assign(fsrc + (size_t)step * R, fsrc + (size_t)(step + 1) * R);
@@ -652,10 +678,10 @@ void DecodeTask::run_forced(int n_audio, int n_steps, const int32_t* ftok, const
         sp->pos_idx = position_quirk ? i : S + i - 1;
         sp->parity = i & 1; sp->first_step = 0; sp->want_no_speech = 0; sp->n_rows = R;
         for (int r = 0; r < R; ++r) {
-            WRS_REQUIRE(rows[r].back() >= 0 && rows[r].back() < m->V, "run_forced: token out of range");
-            st.tokens_h()[r] = (int)rows[r].back();
+            WRS_REQUIRE(seqs.back(rows[r]) >= 0 && seqs.back(rows[r]) < m->V, "run_forced: token out of range");
+            st.tokens_h()[r] = (int)seqs.back(rows[r]);
             st.src_h()[r] = sources[r];
-            st.tsmode_h()[r] = timestamps ? ts_mode_of(rows[r], S, ids.ts_begin) : 0;
+            st.tsmode_h()[r] = timestamps ? ts_mode_of(seqs, rows[r], S, ids.ts_begin) : 0;
         }
         step_decode(R);
         memcpy(out_lp + (size_t)i * R * k, st.topk_lp(), (size_t)R * k * 4);
@@ -673,29 +699,29 @@ void DecodeTask::finalize(int n_audio, wrs_decode_result* out) {
     std::vector<std::vector<FinishedSeq>> cands(n_audio);
     for (int i = 0; i < n_audio; ++i) {
         if (mode == WRS_EXTRACT_BEAM_SEARCH) {
-            auto& seqs = finished[i];
-            if ((int)seqs.size() < G) {
+            auto& fin = finished[i];
+            if ((int)fin.size() < G) {
                 std::vector<int> order(G);
                 for (int j = 0; j < G; ++j) order[j] = j;
                 std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sum_logprobs[i * G + a] < sum_logprobs[i * G + b]; });
                 for (int t = G - 1; t >= 0; --t) {
                     const int j = order[t];
                     FinishedSeq f;
-                    f.tokens = rows[i * G + j];
+                    seqs.materialize(rows[i * G + j], f.tokens);
                     f.tokens.push_back(ids.eot);
                     f.score = (double)sum_logprobs[i * G + j];
                     bool found = false;
-                    for (auto& e : seqs)
+                    for (auto& e : fin)
                         if (e.tokens == f.tokens) { e.score = f.score; found = true; break; }
-                    if (!found) seqs.push_back(std::move(f));
-                    if ((int)seqs.size() >= G) break;
+                    if (!found) fin.push_back(std::move(f));
+                    if ((int)fin.size() >= G) break;
                 }
             }
-            cands[i] = seqs;
+            cands[i] = fin;
         } else {
             for (int j = 0; j < G; ++j) {
                 FinishedSeq f;
-                f.tokens = rows[i * G + j];
+                seqs.materialize(rows[i * G + j], f.tokens);
                 f.tokens.push_back(ids.eot);
                 f.score = (double)sum_logprobs[i * G + j];
                 cands[i].push_back(std::move(f));

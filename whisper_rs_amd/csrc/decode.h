@@ -10,6 +10,49 @@ struct FinishedSeq {
     double score;
 };
 
+// Token histories of the decoder rows as a prefix tree.  Beam search only ever extends or forks sequences (a new row is
+// its parent's sequence plus one token: beam_search.rs:57-62,88-96), so a row is a node id and a step appends R nodes
+// instead of copying R whole sequences (1280 rows x up to 227 tokens per step at the benchmark's batch).  The reference
+// keys its candidate map by the full token vector (beam_search.rs:60-77); `equal` is that comparison, exact: the 64-bit
+// prefix hash only rejects early, a match is confirmed token by token down to the first shared node.
+struct SeqStore {
+    struct Node { int32_t parent; int32_t len; int64_t token; uint64_t hash; };
+    std::vector<Node> nodes;
+    void clear() { nodes.clear(); }
+    void reserve(size_t n) { nodes.reserve(n); }
+    int append(int parent, int64_t token) {
+        const uint64_t ph = parent >= 0 ? nodes[parent].hash : 0x9e3779b97f4a7c15ull;
+        uint64_t z = ph ^ ((uint64_t)token + 0x9e3779b97f4a7c15ull + (ph << 6) + (ph >> 2));
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        z ^= z >> 31;
+        nodes.push_back({(int32_t)parent, parent >= 0 ? nodes[parent].len + 1 : 1, token, z});
+        return (int)nodes.size() - 1;
+    }
+    int chain(const std::vector<int64_t>& tokens) {
+        int id = -1;
+        for (int64_t t : tokens) id = append(id, t);
+        return id;
+    }
+    int64_t back(int id) const { return nodes[id].token; }
+    int len(int id) const { return id >= 0 ? nodes[id].len : 0; }
+    int parent(int id) const { return nodes[id].parent; }
+    bool equal(int a, int b) const {
+        if (a == b) return true;
+        if (a < 0 || b < 0 || nodes[a].len != nodes[b].len || nodes[a].hash != nodes[b].hash) return false;
+        while (a != b) {
+            if (nodes[a].token != nodes[b].token) return false;
+            a = nodes[a].parent;
+            b = nodes[b].parent;
+        }
+        return true;
+    }
+    void materialize(int id, std::vector<int64_t>& out) const {
+        out.resize((size_t)len(id));
+        for (int q = len(id) - 1; q >= 0; --q, id = nodes[id].parent) out[q] = nodes[id].token;
+    }
+};
+
 struct DecodeTask {
     Model* m = nullptr;
     wrs_token_ids ids{};
@@ -43,8 +86,10 @@ struct DecodeTask {
     DevBuf audio_dev, mel_dev;
 
     // host sequencer state
-    std::vector<std::vector<int64_t>> rows;  // [R] token history incl. prompt
-    std::vector<std::vector<int64_t>> scratch_rows;  // next step's rows (swapped with `rows`; capacities are kept)
+    SeqStore seqs;                           // token histories incl. prompt
+    std::vector<int> rows;                   // [R] node of row r in `seqs`
+    std::vector<int> scratch_rows;           // next step's rows (swapped with `rows`)
+    void init_rows(int n_audio);             // every beam of audio a starts at the audio's prompt (decode/mod.rs:297-313)
     std::vector<float> scratch_slp;
     std::vector<int> scratch_src;
     std::vector<float> sum_logprobs;         // [R] (f32 like the reference's tensor)
@@ -69,7 +114,7 @@ struct DecodeTask {
     const int32_t* forced_src = nullptr;
     const float* forced_slp = nullptr;
     void record_candidates(int R, bool step0);
-    void apply_forced(int step, const std::vector<std::vector<int64_t>>& old_rows);
+    void apply_forced(int step, const std::vector<int>& old_rows);
 
     // graph replay of the decode step
     bool use_graph = true;
