@@ -3,7 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := whisper_rs_amd/csrc
 OBJDIR := build/obj
-SRCS := $(CSRC)/common.cpp $(CSRC)/gemm.hip $(CSRC)/gemm_pring.hip $(CSRC)/elementwise.hip $(CSRC)/attention.hip $(CSRC)/logits.hip $(CSRC)/parity_f32.hip $(CSRC)/mel_fused.hip \
+SRCS := $(CSRC)/common.cpp $(CSRC)/gemm.hip $(CSRC)/gemm_pring.hip $(CSRC)/elementwise.hip $(CSRC)/attention.hip $(CSRC)/attn_self_mfma.hip $(CSRC)/logits.hip $(CSRC)/parity_f32.hip $(CSRC)/mel_fused.hip \
         $(CSRC)/mel.cpp $(CSRC)/audio_io.cpp $(CSRC)/tokenizer.cpp $(CSRC)/model.cpp $(CSRC)/weights_io.cpp $(CSRC)/decode.cpp $(CSRC)/transcribe.cpp $(CSRC)/pool.cpp $(CSRC)/capi.cpp $(CSRC)/debug_api.cpp
 OBJS := $(patsubst $(CSRC)/%,$(OBJDIR)/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) include/wrs.h include/wrs_debug.h

@@ -1,0 +1,321 @@
+// Decode self-attention on the matrix cores, one wave per (audio, head), beams de-duplicated (gfx950).
+//
+// Reference: MultiHeadAttention::forward_ext on the self-attention K/V cache (model.rs:158-206), with the cache re-indexed
+// by beam search every step (Cached::update_cache, model.rs:53-62; beam_search.rs:111-117).  The cache is never moved
+// here: the ancestry table anc[row][position] names the physical row that holds (row, position) (elementwise.hip).
+//
+// attn_self_kernel (attention.hip) gives every (row, head) its own wave, so the G beams of an audio each pull the history
+// they SHARE (common beam prefixes: 2.4x duplication at beam 5, profiles/r01_pmc_fetch_write_b256.json) from L2 again and do
+// their dot products on the vector ALU (63 % VALU-busy, 79 us per layer at 1280 rows).  Here:
+//   * once per STEP (the table is the same for all layers) self_keys_kernel lists, per audio, every DISTINCT
+//     (position, physical row) pair of the G beams' histories with the set of beams that own it: entry = t | row << 9 | beams << 12;
+//   * one wave per (audio, head) walks that list in blocks of 32 keys: K rows gathered straight into MFMA A-operand
+//     fragments (a key's 64 dims are contiguous), S^T = K Q^T for all beams at once (the beams are the 16-wide query tile,
+//     as in the cross-attention kernel), scores of pairs a beam does not own masked out, online softmax in fp32, and
+//     O^T += V^T P^T with V^T read through LDS by ds_read_b64_tr_b16 (the PV product sums over KEYS, which are rows in memory);
+//   * the new token's q / k / v come from the QKV GEMM's split-K slabs (bias, scale, cache append fused as before) and
+//     form the first key block (every beam owns exactly its own new key, so the running max is finite from then on).
+// Every distinct K/V row is fetched once per (audio, head): L2->CU traffic equals the HBM traffic.
+#include "kernels.h"
+
+namespace wrs {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+static constexpr float SK_NEG = -1.0e30f;  // "masked": finite, so a query tile column with no owned key never produces inf - inf
+
+// ------------------------------------------------------------------------------------------ per-step key list
+// klist[audio][0] = number of entries, [1 ..]: distinct (t, row) pairs of positions 0 .. cache_pos - 1 in position order
+// (kcount[audio]: the same count, for the host / tests).
+__global__ __launch_bounds__(256) void self_keys_kernel(const int* __restrict__ anc_base, int64_t anc_buf_stride, int n_ctx, int G,
+                                                        const StepParams* __restrict__ sp, int* __restrict__ klist, int klist_stride,
+                                                        int* __restrict__ kcount) {
+    __shared__ int wave_tot[4];
+    const int a = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int cpos = sp->cache_pos;
+    const int* anc = anc_base + (int64_t)sp->parity * anc_buf_stride + (int64_t)a * G * n_ctx;
+    int* out = klist + (int64_t)a * klist_stride;
+    int base = 0;
+    for (int t0 = 0; t0 < cpos; t0 += 256) {  // block-uniform trip count
+        const int t = t0 + tid;
+        int ent[8], n = 0;
+        if (t < cpos) {
+            int r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = j < G ? anc[j * n_ctx + t] - a * G : -1 - j;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j >= G) continue;
+                bool first = true;
+                int mask = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (r[i] == r[j]) {
+                        if (i < j) first = false;
+                        mask |= 1 << i;
+                    }
+                }
+                if (first) ent[n++] = t | ((r[j] & 7) << 9) | (mask << 12);
+            }
+        }
+        int incl = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) woff += wave_tot[w];
+            tot += wave_tot[w];
+        }
+        const int off = base + woff + incl - n;
+        for (int i = 0; i < n; ++i) out[1 + off + i] = ent[i];
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        kcount[a] = base;
+        out[0] = base;  // the attention kernel reads count and first entries with one round trip
+    }
+}
+
+void launch_self_keys(const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_audio, int G, const StepParams* sp, int* klist,
+                      int klist_stride, int* kcount, hipStream_t s) {
+    WRS_REQUIRE(G >= 1 && G <= 8 && n_ctx <= 512 && n_audio >= 1 && klist_stride >= G * n_ctx + 1, "self_keys: bad shape (G %d, n_ctx %d)", G, n_ctx);
+    self_keys_kernel<<<n_audio, 256, 0, s>>>(anc_base, anc_buf_stride, n_ctx, G, sp, klist, klist_stride, kcount);
+}
+
+// ------------------------------------------------------------------------------------------ attention
+struct SelfMfmaParams {
+    const float* slab;   // [ksplit][m_pad][3D] fp32 split-K partial sums of the QKV projection
+    int ksplit, m_pad;
+    const float* bias;   // [3D]
+    float scale;
+    half_t* kc;          // [rows][n_ctx][D]
+    half_t* vc;
+    int n_ctx, G, H, D;
+    const StepParams* sp;
+    const int* klist;
+    int klist_stride;
+    const int* kcount;
+    half_t* out;         // packed activation order
+};
+
+static constexpr int SM_VIMG = 4096;              // V image: 32 keys x 128 B, 16-byte chunks XOR-swizzled with (key & 7)
+static constexpr int SM_STAGE = 2048;             // 16 rows x 128 B: q, then the new keys
+static constexpr int SM_WAVE = SM_VIMG + SM_STAGE + 64;  // + 32 beam masks
+
+__device__ __forceinline__ int vimg_off(int key, int chunk) { return key * 128 + ((chunk ^ (key & 7)) << 4); }
+
+__device__ __forceinline__ void slab_sum8(const float* __restrict__ slab, int ksplit, int64_t slab_stride, int64_t off,
+                                          const float* __restrict__ bias, int col, float (&o)[8]) {
+    floatx4 a0 = *reinterpret_cast<const floatx4*>(slab + off), a1 = *reinterpret_cast<const floatx4*>(slab + off + 4);
+    for (int sidx = 1; sidx < ksplit; ++sidx) {
+        a0 += *reinterpret_cast<const floatx4*>(slab + sidx * slab_stride + off);
+        a1 += *reinterpret_cast<const floatx4*>(slab + sidx * slab_stride + off + 4);
+    }
+    a0 += *reinterpret_cast<const floatx4*>(bias + col);
+    a1 += *reinterpret_cast<const floatx4*>(bias + col + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o[j] = a0[j];
+        o[4 + j] = a1[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4][SM_WAVE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hgroups = (p.H + 3) >> 2;
+    const int a = (int)blockIdx.x / hgroups, h = ((int)blockIdx.x % hgroups) * 4 + wave;
+    if (h >= p.H) return;  // the kernel has no workgroup barrier: every wave works on its own LDS slice
+    unsigned char* my = lds[wave];
+    unsigned char* vimg = my;
+    unsigned char* stage = my + SM_VIMG;
+    unsigned char* mbuf = my + SM_VIMG + SM_STAGE;
+    const int qcol = lane & 15, qg = lane >> 4;
+    const int G = p.G, D = p.D;
+    const int cpos = p.sp->cache_pos;
+    const int* list = p.klist + (int64_t)a * p.klist_stride;
+    const int count = list[0];
+    const int nb = (count + 31) >> 5;
+    const unsigned row_stride_b = (unsigned)(p.n_ctx * D * 2);
+    const unsigned audio_b = (unsigned)(a * G) * row_stride_b + (unsigned)(h * 128);
+    const char* kcb = reinterpret_cast<const char*>(p.kc);
+    const char* vcb = reinterpret_cast<const char*>(p.vc);
+
+    // requests of key block 0 first: they fly while the new token is prepared
+    half8 kf[4], vf[4];
+    int e_cur = 0, e_nxt = 0;
+    auto entry_of = [&](int kb) -> int {  // requested without waiting for `count` (the list buffer covers every index asked for)
+        const int idx = kb * 32 + (lane & 31);
+        const int e = list[1 + min(idx, p.klist_stride - 2)];
+        return idx < count ? e : 0;  // 0 = (t 0, first row of the audio, no owner): a valid address, masked out
+    };
+    auto issue = [&](int e) {
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+            const int ek = __shfl(e, tile * 16 + qcol);
+            const unsigned boff = audio_b + (unsigned)((ek >> 9) & 7) * row_stride_b + (unsigned)(ek & 511) * (unsigned)(D * 2);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[tile * 2 + ks] = *reinterpret_cast<const half8*>(kcb + boff + (ks * 4 + qg) * 16);
+                vf[tile * 2 + ks] = *reinterpret_cast<const half8*>(vcb + boff + (ks * 4 + qg) * 16);
+            }
+        }
+    };
+    e_cur = entry_of(0);
+    e_nxt = entry_of(1);
+    if (nb > 0) issue(e_cur);
+
+    // ---- the new token of every beam: q, k, v from the slabs (+ bias, scale), k / v appended to the cache
+    half8 qf[2], knf[2];
+    {
+        const int beam = lane >> 3, c = lane & 7;
+        half8 q16 = {0, 0, 0, 0, 0, 0, 0, 0}, k16 = q16, v16 = q16;
+        if (beam < G) {
+            const int row = a * G + beam, col = h * 64 + c * 8;
+            const int64_t ss = (int64_t)p.m_pad * 3 * D, off = (int64_t)row * 3 * D + col;
+            float qv[8], kn[8], vn[8];
+            slab_sum8(p.slab, p.ksplit, ss, off, p.bias, col, qv);
+            slab_sum8(p.slab, p.ksplit, ss, off + D, p.bias, D + col, kn);
+            slab_sum8(p.slab, p.ksplit, ss, off + 2 * D, p.bias, 2 * D + col, vn);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                q16[j] = (_Float16)(qv[j] * p.scale);
+                k16[j] = (_Float16)(kn[j] * p.scale);
+                v16[j] = (_Float16)vn[j];
+            }
+            const int64_t coff = ((int64_t)row * p.n_ctx + cpos) * D + col;
+            *reinterpret_cast<half8*>(p.kc + coff) = k16;
+            *reinterpret_cast<half8*>(p.vc + coff) = v16;
+        }
+        const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        // q -> stage rows 0..7 (zero for beam >= G), rows 8..15 zero; read back as the B operand Q[query][dims]
+        *reinterpret_cast<half8*>(stage + beam * 128 + c * 16) = q16;
+        *reinterpret_cast<half8*>(stage + (8 + beam) * 128 + c * 16) = zero;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const half8*>(stage + qcol * 128 + (ks * 4 + qg) * 16);
+        // new keys -> the same rows (LDS operations of a wave execute in order), read back as the A operand K[key][dims]
+        *reinterpret_cast<half8*>(stage + beam * 128 + c * 16) = k16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) knf[ks] = *reinterpret_cast<const half8*>(stage + qcol * 128 + (ks * 4 + qg) * 16);
+        // new values -> V image rows 0..7, rows 8..31 zero (0 x garbage could be NaN), masks: key b is owned by beam b
+        *reinterpret_cast<half8*>(vimg + vimg_off(beam, c)) = v16;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = i * 64 + lane;  // 24 rows x 8 chunks
+            *reinterpret_cast<half8*>(vimg + vimg_off(8 + (idx >> 3), idx & 7)) = zero;
+        }
+        if (lane < 32) mbuf[lane] = (unsigned char)(lane < G ? (1 << lane) : 0);
+    }
+
+    floatx4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float m_run = SK_NEG, l_run = 0.f;
+
+    // one 32-key block, second half: masks, online softmax, P.V (V image and masks are in LDS)
+    auto block = [&](const floatx4 s0, const floatx4 s1) {
+        const unsigned m0 = *reinterpret_cast<const unsigned*>(mbuf + 4 * qg);
+        const unsigned m1 = *reinterpret_cast<const unsigned*>(mbuf + 16 + 4 * qg);
+        float sv[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sv[j] = (((m0 >> (8 * j)) & 0xffu) >> qcol) & 1u ? s0[j] : SK_NEG;
+            sv[4 + j] = (((m1 >> (8 * j)) & 0xffu) >> qcol) & 1u ? s1[j] : SK_NEG;
+        }
+        float bm = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+        bm = fmaxf(bm, __shfl_xor(bm, 16));
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float m_new = fmaxf(m_run, bm);
+        const float alpha = __expf(m_run - m_new);
+        float ps = 0.f;
+        half8 pf, pl;  // probabilities as fp16 hi + lo parts: the P.V product keeps ~22 bits of P, like the fp32 x fp16 FMAs of attn_self_kernel
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float e = __expf(sv[j] - m_new);  // masked: exp(-1e30 - m) = 0 once the column has seen an owned key
+            ps += e;
+            pf[j] = (_Float16)e;
+            pl[j] = (_Float16)(e - (float)pf[j]);
+        }
+        ps += __shfl_xor(ps, 16);
+        ps += __shfl_xor(ps, 32);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+        // V^T fragments: lane (dim d = qcol of tile dt, key group qg) needs V[keys 4qg..4qg+3 | 16+4qg..][dt*16 + d]: two
+        // transposed 4x16 block reads; lane 4q+p of a 16-lane group supplies the address of row q, columns 4p..4p+3
+        const int tq = qcol >> 2, tp = qcol & 3;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int chunk = 2 * dt + (tp >> 1);
+            const int key0 = 4 * qg + tq, key1 = 16 + 4 * qg + tq;
+            const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4v*)(vimg + vimg_off(key0, chunk) + 8 * (tp & 1)));
+            const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4v*)(vimg + vimg_off(key1, chunk) + 8 * (tp & 1)));
+            const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
+            const half8 vfrag = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+            o[dt] *= alpha;
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pf, o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pl, o[dt], 0, 0, 0);
+        }
+    };
+
+    {   // block of the new keys (tile 1 is empty: its masks are 0)
+        floatx4 s0 = floatx4{0.f, 0.f, 0.f, 0.f};
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(knf[0], qf[0], s0, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(knf[1], qf[1], s0, 0, 0, 0);
+        block(s0, floatx4{0.f, 0.f, 0.f, 0.f});
+    }
+    for (int kb = 0; kb < nb; ++kb) {
+        // this block's V rows -> LDS image (the previous block's transposed reads were consumed by its MFMAs), masks
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) *reinterpret_cast<half8*>(vimg + vimg_off(tile * 16 + qcol, ks * 4 + qg)) = vf[tile * 2 + ks];
+        if (lane < 32) mbuf[lane] = (unsigned char)((e_cur >> 12) & 0xff);
+        // S^T = K Q^T (two 16-key tiles), then the next block's requests into the same registers
+        floatx4 s0 = floatx4{0.f, 0.f, 0.f, 0.f}, s1 = floatx4{0.f, 0.f, 0.f, 0.f};
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[0], s0, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2], qf[0], s1, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[3], qf[1], s1, 0, 0, 0);
+        e_cur = e_nxt;
+        if (kb + 1 < nb) {
+            issue(e_cur);
+            e_nxt = entry_of(kb + 2);
+        }
+        block(s0, s1);
+    }
+
+    // O^T: lane holds dims dt*16 + 4 qg + r of query (beam) qcol
+    if (qcol < G) {
+        const float inv = 1.f / l_run;
+        const int row = a * G + qcol;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<half4*>(p.out + pa_off(row, h * 64 + dt * 16 + 4 * qg, D >> 5)) =
+                half4{(_Float16)(o[dt][0] * inv), (_Float16)(o[dt][1] * inv), (_Float16)(o[dt][2] * inv), (_Float16)(o[dt][3] * inv)};
+    }
+}
+
+void launch_attn_self_mfma(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc, int n_ctx,
+                           int n_rows, int G, int H, int D, const StepParams* sp, const int* klist, int klist_stride, const int* kcount,
+                           half_t* out, hipStream_t s) {
+    WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && qkv_slab && qkv_bias && ksplit >= 1, "attn_self_mfma: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
+    WRS_REQUIRE(G >= 1 && G <= 8 && n_rows % G == 0 && klist && kcount, "attn_self_mfma: bad group size %d for %d rows", G, n_rows);
+    WRS_REQUIRE((int64_t)n_rows * n_ctx * D * 2 < (1ll << 32), "attn_self_mfma: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
+    SelfMfmaParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, n_ctx, G, H, D, sp, klist, klist_stride, kcount, out};
+    const int n_audio = n_rows / G;
+    attn_self_mfma_kernel<<<n_audio * ((H + 3) / 4), 256, 0, s>>>(p);
+}
+
+}  // namespace wrs

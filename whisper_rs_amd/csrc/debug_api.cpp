@@ -122,6 +122,20 @@ int wrs_debug_attn_self_run(wrs_debug_attn_self* a) {
         HIP_CHECK(hipMemcpyAsync(sp.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
         anc.alloc((size_t)2 * R * a->n_ctx * 4);
         HIP_CHECK(hipMemcpyAsync(anc.p, a->anc, (size_t)R * a->n_ctx * 4, hipMemcpyDeviceToDevice, s));
+        if (a->q16_mode == 2) {  // beam-de-duplicating MFMA form (attn_self_mfma.hip): key list of this ancestry table first
+            WRS_REQUIRE(a->rows_per_audio <= 8, "wrs_debug_attn_self_run: the MFMA form takes at most 8 rows per audio");
+            const int n_audio = R / a->rows_per_audio, stride = a->rows_per_audio * a->n_ctx + 1;
+            DevBuf klist, kcount;
+            klist.alloc((size_t)n_audio * stride * 4);
+            kcount.alloc((size_t)n_audio * 4);
+            launch_self_keys(anc.as<int>(), (int64_t)R * a->n_ctx, a->n_ctx, n_audio, a->rows_per_audio, sp.as<StepParams>(), klist.as<int>(), stride,
+                             kcount.as<int>(), s);
+            launch_attn_self_mfma(a->qkv, 1, R, a->qkv_bias, a->scale, reinterpret_cast<half_t*>(a->kc), reinterpret_cast<half_t*>(a->vc), a->n_ctx, R,
+                                  a->rows_per_audio, a->H, a->D, sp.as<StepParams>(), klist.as<int>(), stride, kcount.as<int>(),
+                                  reinterpret_cast<half_t*>(a->out_packed), s);
+            HIP_CHECK(hipStreamSynchronize(s));
+            return;
+        }
         if (a->q16_mode) {
             // the >= 480-row form: q as fp16 [R, D] and the new k / v already in the cache (what the QKV GEMM's epilogue leaves);
             // prepared on the host from the same qkv / bias / scale

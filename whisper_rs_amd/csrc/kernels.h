@@ -225,6 +225,14 @@ void launch_attn_self_q16(const half_t* q16, half_t* kc, half_t* vc, const int* 
                           int rows_per_audio, int phys_mul, int H, int D, const StepParams* sp, half_t* out, hipStream_t s);
 // cross-attention with the query projection given as fp16 [n_audio * G, D] (bias and scale applied)
 void launch_attn_cross_q16(const half_t* q16, const half_t* kp, const half_t* vp, int n_audio, int G, int T, int H, half_t* out, hipStream_t s);
+// beam-de-duplicating form on the matrix cores (attn_self_mfma.hip): one wave per (audio, head) over the distinct
+// (position, physical row) pairs of the G beams' histories.  launch_self_keys builds that list once per step (it depends on
+// the ancestry table only): klist [n_audio][klist_stride >= G * n_ctx], kcount [n_audio]; phys_mul must be 1.
+void launch_self_keys(const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_audio, int G, const StepParams* sp, int* klist,
+                      int klist_stride, int* kcount, hipStream_t s);
+void launch_attn_self_mfma(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc, int n_ctx,
+                           int n_rows, int G, int H, int D, const StepParams* sp, const int* klist, int klist_stride, const int* kcount,
+                           half_t* out, hipStream_t s);
 void launch_anc_init(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_phys_rows, int G, hipStream_t s);
 void launch_anc_update(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, const StepParams* sp,
                        const int* src, hipStream_t s);

@@ -445,6 +445,8 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.kc.alloc((size_t)L_dec * r_cap * n_ctx * D * 2);
     st.vc.alloc((size_t)L_dec * r_cap * n_ctx * D * 2);
     st.anc.alloc((size_t)2 * r_cap * n_ctx * 4);
+    st.self_keys_stride = (r_cap / std::max(a_cap, 1)) * n_ctx + 1;  // [0] = count
+    st.self_keys.alloc(((size_t)a_cap * st.self_keys_stride + a_cap) * 4);
     st.act_rows = (int)round_up(m_pad, 128);  // packed activations are also read in 128-row tiles by the big GEMM
     st.x.alloc((size_t)m_pad * D * 4);
     st.xn.alloc((size_t)st.act_rows * D * 2);
@@ -470,6 +472,8 @@ void Model::init_state(DecState& st, int a_cap, int group) {
         dec_slab_path = !(e && e[0] == '1');
         e = getenv("WRS_DEC_FUSED");
         dec_fused_tiny = e && e[0] == '1';
+        e = getenv("WRS_SELF_MFMA_MIN_AUDIO");
+        self_mfma_min_audio = e ? atoi(e) : 16;
     }
     if (parity_f32) init_state_f32(st);
 }
@@ -564,6 +568,16 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
         Timed tm(timer, "dec_anc_update", stream);
         launch_anc_update(st.anc.as<int>(), anc_stride, n_ctx, rows, sp, st.src_d(), stream);
     }
+    // many audios with several beams each: self-attention over the DISTINCT (position, row) pairs of an audio's beams, on
+    // the matrix cores (attn_self_mfma.hip); the pair list follows from the ancestry table, once per step for all layers
+    const bool self_mfma = self_mfma_min_audio > 0 && phys_mul == 1 && q_per_audio >= 2 && q_per_audio <= 8 && n_audio >= self_mfma_min_audio &&
+                           q_per_audio * n_ctx + 1 <= st.self_keys_stride;
+    int* self_klist = st.self_keys.as<int>();
+    int* self_kcount = self_klist + (size_t)st.a_cap * st.self_keys_stride;
+    if (self_mfma) {
+        Timed tm(timer, "dec_self_keys", stream);
+        launch_self_keys(st.anc.as<int>(), anc_stride, n_ctx, n_audio, q_per_audio, sp, self_klist, st.self_keys_stride, self_kcount, stream);
+    }
     {
         Timed tm(timer, "dec_embed_ln", stream);
         launch_embed_ln(emb16, dec_pos, sp, st.tokens_d(), dec[0].attn_ln_g, dec[0].attn_ln_b, rows, D, st.x.as<float>(),
@@ -575,8 +589,12 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
         gemm_slab("dec_gemm_qkv", st.xn.as<half_t>(), b.qkv_w, 3 * D, D, ks_qkv, 3 * wD);
         {
             Timed tm(timer, "dec_attn_self", stream);
-            launch_attn_self(slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer,
-                             st.anc.as<int>(), anc_stride, n_ctx, rows, q_per_audio, phys_mul, H, D, sp, st.att.as<half_t>(), stream);
+            if (self_mfma)
+                launch_attn_self_mfma(slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer, n_ctx,
+                                      rows, q_per_audio, H, D, sp, self_klist, st.self_keys_stride, self_kcount, st.att.as<half_t>(), stream);
+            else
+                launch_attn_self(slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer,
+                                 st.anc.as<int>(), anc_stride, n_ctx, rows, q_per_audio, phys_mul, H, D, sp, st.att.as<half_t>(), stream);
         }
         gemm_slab("dec_gemm_out", st.att.as<half_t>(), b.out_w, D, D, ks_d, wD);
         {
