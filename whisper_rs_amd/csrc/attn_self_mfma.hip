@@ -25,6 +25,21 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
+// reductions over the lanes l, l^16, l^32, l^48 (the four key groups of a query column) with v_permlane32_swap /
+// v_permlane16_swap instead of two ds_bpermute round trips each
+__device__ __forceinline__ float rows_max(float x) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 static constexpr float SK_NEG = -1.0e30f;  // "masked": finite, so a query tile column with no owned key never produces inf - inf
 
 // ------------------------------------------------------------------------------------------ per-step key list
@@ -180,6 +195,7 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
     {
         const int beam = lane >> 3, c = lane & 7;
         half8 q16 = {0, 0, 0, 0, 0, 0, 0, 0}, k16 = q16, v16 = q16;
+        const float qscale = p.scale * 1.44269504088896341f;  // scores in the log2 domain: the softmax below is exp2 (one v_exp_f32 each)
         if (beam < G) {
             const int row = a * G + beam, col = h * 64 + c * 8;
             const int64_t ss = (int64_t)p.m_pad * 3 * D, off = (int64_t)row * 3 * D + col;
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
             slab_sum8(p.slab, p.ksplit, ss, off + 2 * D, p.bias, 2 * D + col, vn);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                q16[j] = (_Float16)(qv[j] * p.scale);
+                q16[j] = (_Float16)(qv[j] * qscale);
                 k16[j] = (_Float16)(kn[j] * p.scale);
                 v16[j] = (_Float16)vn[j];
             }
@@ -233,22 +249,21 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
             sv[4 + j] = (((m1 >> (8 * j)) & 0xffu) >> qcol) & 1u ? s1[j] : SK_NEG;
         }
         float bm = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-        bm = fmaxf(bm, __shfl_xor(bm, 16));
-        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        bm = rows_max(bm);
         const float m_new = fmaxf(m_run, bm);
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float ps = 0.f;
         half8 pf, pl;  // probabilities as fp16 hi + lo parts: the P.V product keeps ~22 bits of P, like the fp32 x fp16 FMAs of attn_self_kernel
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float e = __expf(sv[j] - m_new);  // masked: exp(-1e30 - m) = 0 once the column has seen an owned key
+            const float e = __builtin_amdgcn_exp2f(sv[j] - m_new);  // masked: exp2(-1e30 - m) = 0 once the column has seen an owned key
             ps += e;
             pf[j] = (_Float16)e;
             pl[j] = (_Float16)(e - (float)pf[j]);
         }
-        ps += __shfl_xor(ps, 16);
-        ps += __shfl_xor(ps, 32);
+        ps = rows_sum(ps);
         l_run = l_run * alpha + ps;
+        const bool moved = __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;  // wave-uniform: rescale only when some column's max moved
         m_run = m_new;
         // V^T fragments: lane (dim d = qcol of tile dt, key group qg) needs V[keys 4qg..4qg+3 | 16+4qg..][dt*16 + d]: two
         // transposed 4x16 block reads; lane 4q+p of a 16-lane group supplies the address of row q, columns 4p..4p+3
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
                 (__attribute__((address_space(3))) short4v*)(vimg + vimg_off(key1, chunk) + 8 * (tp & 1)));
             const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
             const half8 vfrag = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
-            o[dt] *= alpha;
+            if (moved) o[dt] *= alpha;
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pf, o[dt], 0, 0, 0);
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pl, o[dt], 0, 0, 0);
         }
