@@ -55,6 +55,23 @@ def test_beam_search_decode_vs_oracle(gpu, dims_name, n_audio, sample_len):
     task.close()
 
 
+def test_beam_search_decode_with_mfma_self_attention(gpu, monkeypatch):
+    """the beam-de-duplicating MFMA self-attention (csrc/attn_self_mfma.hip: what the benchmark runs; by default from 16
+    audios per step) on a 3-audio beam-5 decode and a 2-audio beam-3 decode with a length penalty: free-running vs the oracle."""
+    monkeypatch.setenv("WRS_SELF_MFMA_MIN_AUDIO", "1")  # read when a decoder state is created
+    mel = mel_windows(3)
+    view, _ = _oracle_run("micro", mel, oracle_decode_options(sample_len=40, beam_size=5))
+    task = gpu.DecodeTask(gpu_model(gpu, "micro"), TokenIds.english(), gpu.DecodeOptions(sample_len=40, max_audio=3))
+    _free_run("micro_beam5_x3_mfma_self", task, mel, view, 5)
+    task.close()
+    mel = mel_windows(2)
+    view, _ = _oracle_run("nano", mel, oracle_decode_options(sample_len=24, beam_size=3, len_penalty=0.8))
+    task = gpu.DecodeTask(gpu_model(gpu, "nano"), TokenIds.english(),
+                          gpu.DecodeOptions(sample_len=24, max_audio=2, token_extract_mode=gpu.TokenExtractMode.BeamSearch(3, 1.0), len_penalty=0.8))
+    _free_run("nano_beam3_x2_mfma_self", task, mel, view, 3)
+    task.close()
+
+
 def test_greedy_equals_beam1(gpu):
     """greedy (unreachable in the reference) == greedy.rs update + one EOT pad; token-equal to beam_size 1."""
     mel = mel_windows(2)
