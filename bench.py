@@ -261,7 +261,19 @@ def main():
     if use_dist:  # launched by torch.distributed.run: one rank per GPU, RCCL only for barrier + MAX
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a banner ("Hostname : ...", "Librccl path : ...") on STDOUT when its communicator is created (at init or
+        # at the first collective): keep stdout to the one JSON line by pointing fd 1 at stderr until that has happened
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     import whisper_rs_amd as W
     from whisper_rs_amd import synth
