@@ -169,10 +169,12 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
     // requests of key block 0 first: they fly while the new token is prepared
     half8 kf[4], vf[4];
     int e_cur = 0, e_nxt = 0;
-    auto entry_of = [&](int kb) -> int {  // requested without waiting for `count` (the list buffer covers every index asked for)
-        const int idx = kb * 32 + (lane & 31);
-        const int e = list[1 + min(idx, p.klist_stride - 2)];
-        return idx < count ? e : 0;  // 0 = (t 0, first row of the audio, no owner): a valid address, masked out
+    // list entries are requested without waiting for `count` (the buffer covers every index asked for) and validated only
+    // when used: a select on the freshly loaded value would make the compiler wait for it — and, loads returning in order,
+    // for every K / V request issued before it
+    auto entry_raw = [&](int kb) -> int { return list[1 + min(kb * 32 + (lane & 31), p.klist_stride - 2)]; };
+    auto entry_ok = [&](int kb, int e) -> int {
+        return kb * 32 + (lane & 31) < count ? e : 0;  // 0 = (t 0, first row of the audio, no owner): a valid address, masked out
     };
     auto issue = [&](int e) {
 #pragma unroll
@@ -186,8 +188,8 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
             }
         }
     };
-    e_cur = entry_of(0);
-    e_nxt = entry_of(1);
+    e_nxt = entry_raw(1);
+    e_cur = entry_ok(0, entry_raw(0));
     if (nb > 0) issue(e_cur);
 
     // ---- the new token of every beam: q, k, v from the slabs (+ bias, scale), k / v appended to the cache
@@ -303,10 +305,10 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
         s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2], qf[0], s1, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[3], qf[1], s1, 0, 0, 0);
-        e_cur = e_nxt;
+        e_cur = entry_ok(kb + 1, e_nxt);
         if (kb + 1 < nb) {
+            e_nxt = entry_raw(kb + 2);  // requested BEFORE the block's rows: waiting for it later does not wait for them
             issue(e_cur);
-            e_nxt = entry_of(kb + 2);
         }
         block(s0, s1);
     }
