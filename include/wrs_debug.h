@@ -86,7 +86,8 @@ typedef struct wrs_debug_attn_self {
     const int32_t* anc;      /* [n_rows][n_ctx]: physical row holding (row, position) */
     void* out_packed;        /* fp16 packed-activation order, round_up(n_rows,128) x D */
     int32_t q16_mode;        /* 1: the >= 480-row form of the kernel (q as fp16, new k / v already in the cache);
-                              * 2: the beam-de-duplicating MFMA kernel (attn_self_mfma.hip; rows_per_audio <= 8) */
+                              * 2: the beam-de-duplicating MFMA kernel (attn_self_mfma.hip; rows_per_audio <= 8);
+                              * 3: the same kernel in its >= 480-row form (q as fp16, new k / v in the cache and in the key list) */
 } wrs_debug_attn_self;
 int wrs_debug_attn_self_run(wrs_debug_attn_self* a);
 

@@ -58,7 +58,7 @@ def test_cross_attention_kernel(gpu, n_audio, G, q16_mode):
     assert err < TOL
 
 
-@pytest.mark.parametrize("q16_mode", [0, 1, 2], ids=["slab_qkv", "fp16_q", "mfma_dedup"])
+@pytest.mark.parametrize("q16_mode", [0, 1, 2, 3], ids=["slab_qkv", "fp16_q", "mfma_dedup", "mfma_dedup_fp16_q"])
 @pytest.mark.parametrize("n_rows,G,cache_pos", [(1280, 5, 447), (1280, 5, 112), (1280, 5, 0), (1280, 5, 1), (30, 5, 31), (30, 5, 32),
                                                 (30, 5, 33), (12, 1, 200), (21, 7, 64), (16, 8, 100), (1280, 5, 224)])
 def test_self_attention_kernel(gpu, n_rows, G, cache_pos, q16_mode):
@@ -93,7 +93,7 @@ def test_self_attention_kernel(gpu, n_rows, G, cache_pos, q16_mode):
     got = DBG.unpack_activations(out, n_rows, D)
     x = qkv + bias
     qn = x[:, :D] * scale
-    if q16_mode == 1:
+    if q16_mode in (1, 3):
         qn = qn.to(torch.float16).float()  # the query reaches the kernel as fp16 in this form
     kn = (x[:, D:2 * D] * scale).to(torch.float16)
     vn = x[:, 2 * D:].to(torch.float16)

@@ -47,7 +47,7 @@ static constexpr float SK_NEG = -1.0e30f;  // "masked": finite, so a query tile 
 // (kcount[audio]: the same count, for the host / tests).
 __global__ __launch_bounds__(256) void self_keys_kernel(const int* __restrict__ anc_base, int64_t anc_buf_stride, int n_ctx, int G,
                                                         const StepParams* __restrict__ sp, int* __restrict__ klist, int klist_stride,
-                                                        int* __restrict__ kcount) {
+                                                        int* __restrict__ kcount, int include_new) {
     __shared__ int wave_tot[4];
     const int a = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int cpos = sp->cache_pos;
@@ -95,16 +95,19 @@ __global__ __launch_bounds__(256) void self_keys_kernel(const int* __restrict__ 
         base += tot;
         __syncthreads();
     }
+    // include_new: the step's own position (every beam owns exactly its own new key, already appended to the cache by the
+    // QKV GEMM's epilogue) closes the list; otherwise the attention kernel builds the new keys from the QKV slabs itself
+    if (include_new && tid < G) out[1 + base + tid] = cpos | (tid << 9) | ((1 << tid) << 12);
     if (tid == 0) {
-        kcount[a] = base;
-        out[0] = base;  // the attention kernel reads count and first entries with one round trip
+        kcount[a] = base + (include_new ? G : 0);
+        out[0] = base + (include_new ? G : 0);  // the attention kernel reads count and first entries with one round trip
     }
 }
 
 void launch_self_keys(const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_audio, int G, const StepParams* sp, int* klist,
-                      int klist_stride, int* kcount, hipStream_t s) {
+                      int klist_stride, int* kcount, bool include_new, hipStream_t s) {
     WRS_REQUIRE(G >= 1 && G <= 8 && n_ctx <= 512 && n_audio >= 1 && klist_stride >= G * n_ctx + 1, "self_keys: bad shape (G %d, n_ctx %d)", G, n_ctx);
-    self_keys_kernel<<<n_audio, 256, 0, s>>>(anc_base, anc_buf_stride, n_ctx, G, sp, klist, klist_stride, kcount);
+    self_keys_kernel<<<n_audio, 256, 0, s>>>(anc_base, anc_buf_stride, n_ctx, G, sp, klist, klist_stride, kcount, include_new ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------ attention
@@ -121,6 +124,8 @@ struct SelfMfmaParams {
     int klist_stride;
     const int* kcount;
     half_t* out;         // packed activation order
+    const half_t* q16;   // != null: the query as fp16 [rows, D] (bias and scale applied) and the new keys / values already in the
+                         // cache AND in the key list (QKV GEMM epilogue + self_keys include_new); slab / bias / scale unused
 };
 
 static constexpr int SM_VIMG = 4096;              // V image: 32 keys x 128 B, 16-byte chunks XOR-swizzled with (key & 7)
@@ -194,7 +199,19 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
 
     // ---- the new token of every beam: q, k, v from the slabs (+ bias, scale), k / v appended to the cache
     half8 qf[2], knf[2];
-    {
+    const bool from_slab = p.q16 == nullptr;
+    if (!from_slab) {
+        // B operand Q[query = beam qcol][dims]: straight from the fp16 query buffer; log2(e) folded in for the exp2 softmax
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qcol < G) v = *reinterpret_cast<const half8*>(p.q16 + (int64_t)(a * G + qcol) * D + h * 64 + ks * 32 + 8 * qg);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)v[j] * 1.44269504088896341f);
+            qf[ks] = v;
+            knf[ks] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    } else {
         const int beam = lane >> 3, c = lane & 7;
         half8 q16 = {0, 0, 0, 0, 0, 0, 0, 0}, k16 = q16, v16 = q16;
         const float qscale = p.scale * 1.44269504088896341f;  // scores in the log2 domain: the softmax below is exp2 (one v_exp_f32 each)
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
         }
     };
 
-    {   // block of the new keys (tile 1 is empty: its masks are 0)
+    if (from_slab) {  // block of the new keys (tile 1 is empty: its masks are 0)
         floatx4 s0 = floatx4{0.f, 0.f, 0.f, 0.f};
         s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(knf[0], qf[0], s0, 0, 0, 0);
         s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(knf[1], qf[1], s0, 0, 0, 0);
@@ -324,13 +341,22 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
     }
 }
 
+void launch_attn_self_mfma_q16(const half_t* q16, half_t* kc, half_t* vc, int n_ctx, int n_rows, int G, int H, int D, const StepParams* sp,
+                               const int* klist, int klist_stride, const int* kcount, half_t* out, hipStream_t s) {
+    WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && q16, "attn_self_mfma: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
+    WRS_REQUIRE(G >= 1 && G <= 8 && n_rows % G == 0 && klist && kcount, "attn_self_mfma: bad group size %d for %d rows", G, n_rows);
+    WRS_REQUIRE((int64_t)n_rows * n_ctx * D * 2 < (1ll << 32), "attn_self_mfma: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
+    SelfMfmaParams p{nullptr, 1, 0, nullptr, 1.f, kc, vc, n_ctx, G, H, D, sp, klist, klist_stride, kcount, out, q16};
+    attn_self_mfma_kernel<<<(n_rows / G) * ((H + 3) / 4), 256, 0, s>>>(p);
+}
+
 void launch_attn_self_mfma(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc, int n_ctx,
                            int n_rows, int G, int H, int D, const StepParams* sp, const int* klist, int klist_stride, const int* kcount,
                            half_t* out, hipStream_t s) {
     WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && qkv_slab && qkv_bias && ksplit >= 1, "attn_self_mfma: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
     WRS_REQUIRE(G >= 1 && G <= 8 && n_rows % G == 0 && klist && kcount, "attn_self_mfma: bad group size %d for %d rows", G, n_rows);
     WRS_REQUIRE((int64_t)n_rows * n_ctx * D * 2 < (1ll << 32), "attn_self_mfma: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
-    SelfMfmaParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, n_ctx, G, H, D, sp, klist, klist_stride, kcount, out};
+    SelfMfmaParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, n_ctx, G, H, D, sp, klist, klist_stride, kcount, out, nullptr};
     const int n_audio = n_rows / G;
     attn_self_mfma_kernel<<<n_audio * ((H + 3) / 4), 256, 0, s>>>(p);
 }

@@ -122,17 +122,40 @@ int wrs_debug_attn_self_run(wrs_debug_attn_self* a) {
         HIP_CHECK(hipMemcpyAsync(sp.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
         anc.alloc((size_t)2 * R * a->n_ctx * 4);
         HIP_CHECK(hipMemcpyAsync(anc.p, a->anc, (size_t)R * a->n_ctx * 4, hipMemcpyDeviceToDevice, s));
-        if (a->q16_mode == 2) {  // beam-de-duplicating MFMA form (attn_self_mfma.hip): key list of this ancestry table first
+        if (a->q16_mode == 2 || a->q16_mode == 3) {  // beam-de-duplicating MFMA form (attn_self_mfma.hip): key list of this ancestry table first
             WRS_REQUIRE(a->rows_per_audio <= 8, "wrs_debug_attn_self_run: the MFMA form takes at most 8 rows per audio");
             const int n_audio = R / a->rows_per_audio, stride = a->rows_per_audio * a->n_ctx + 1;
-            DevBuf klist, kcount;
+            const bool direct = a->q16_mode == 3;  // q as fp16, new k / v already in the cache and in the key list
+            DevBuf klist, kcount, qd;
             klist.alloc((size_t)n_audio * stride * 4);
             kcount.alloc((size_t)n_audio * 4);
             launch_self_keys(anc.as<int>(), (int64_t)R * a->n_ctx, a->n_ctx, n_audio, a->rows_per_audio, sp.as<StepParams>(), klist.as<int>(), stride,
-                             kcount.as<int>(), s);
-            launch_attn_self_mfma(a->qkv, 1, R, a->qkv_bias, a->scale, reinterpret_cast<half_t*>(a->kc), reinterpret_cast<half_t*>(a->vc), a->n_ctx, R,
-                                  a->rows_per_audio, a->H, a->D, sp.as<StepParams>(), klist.as<int>(), stride, kcount.as<int>(),
-                                  reinterpret_cast<half_t*>(a->out_packed), s);
+                             kcount.as<int>(), direct, s);
+            if (direct) {  // what the QKV GEMM's epilogue leaves: prepared on the host from the same qkv / bias / scale
+                const int D = a->D;
+                std::vector<float> qkv((size_t)R * 3 * D), bias((size_t)3 * D);
+                HIP_CHECK(hipMemcpy(qkv.data(), a->qkv, qkv.size() * 4, hipMemcpyDeviceToHost));
+                HIP_CHECK(hipMemcpy(bias.data(), a->qkv_bias, bias.size() * 4, hipMemcpyDeviceToHost));
+                std::vector<half_t> q16((size_t)R * D), k16((size_t)D), v16((size_t)D);
+                qd.alloc(q16.size() * 2);
+                for (int r = 0; r < R; ++r) {
+                    for (int c = 0; c < D; ++c) {
+                        q16[(size_t)r * D + c] = (half_t)((qkv[(size_t)r * 3 * D + c] + bias[c]) * a->scale);
+                        k16[c] = (half_t)((qkv[(size_t)r * 3 * D + D + c] + bias[D + c]) * a->scale);
+                        v16[c] = (half_t)(qkv[(size_t)r * 3 * D + 2 * D + c] + bias[2 * D + c]);
+                    }
+                    const size_t off = ((size_t)r * a->n_ctx + a->cache_pos) * D * 2;
+                    HIP_CHECK(hipMemcpy((char*)a->kc + off, k16.data(), (size_t)D * 2, hipMemcpyHostToDevice));
+                    HIP_CHECK(hipMemcpy((char*)a->vc + off, v16.data(), (size_t)D * 2, hipMemcpyHostToDevice));
+                }
+                HIP_CHECK(hipMemcpy(qd.p, q16.data(), q16.size() * 2, hipMemcpyHostToDevice));
+                launch_attn_self_mfma_q16(qd.as<half_t>(), reinterpret_cast<half_t*>(a->kc), reinterpret_cast<half_t*>(a->vc), a->n_ctx, R, a->rows_per_audio,
+                                          a->H, a->D, sp.as<StepParams>(), klist.as<int>(), stride, kcount.as<int>(), reinterpret_cast<half_t*>(a->out_packed), s);
+            } else {
+                launch_attn_self_mfma(a->qkv, 1, R, a->qkv_bias, a->scale, reinterpret_cast<half_t*>(a->kc), reinterpret_cast<half_t*>(a->vc), a->n_ctx, R,
+                                      a->rows_per_audio, a->H, a->D, sp.as<StepParams>(), klist.as<int>(), stride, kcount.as<int>(),
+                                      reinterpret_cast<half_t*>(a->out_packed), s);
+            }
             HIP_CHECK(hipStreamSynchronize(s));
             return;
         }

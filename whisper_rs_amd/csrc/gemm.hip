@@ -116,6 +116,11 @@ struct GemmParams {
     int c_packed;
     int ksplit;              // > 1: blockIdx.y = k-slice, fp32 partial sums go to slab blockIdx.y (no epilogue math)
     int64_t slab_stride;     // floats between slabs
+    int qkv_d_model;         // > 0: decode-step QKV epilogue (GemmEpi)
+    half_t* kcache;
+    half_t* vcache;
+    int64_t cache_row_stride;
+    const StepParams* sp;
 };
 
 // Epilogue of one wave's 64x64 block (acc[i][j]: n = ncolw + 16 i + 4 (lane >> 4) + r, m = mrow0 + 16 j + (lane & 15)).
@@ -134,6 +139,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
             for (int i = 0; i < 4; ++i) {
                 const int n = ncol0 + i * 16;
                 if (n < p.N) *reinterpret_cast<floatx4*>(slab + m * p.ldc + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+    if (p.qkv_d_model > 0) {  // q -> fp16 [M, ldc]; k / v -> the cache row of m at the step's position (launcher checks the shape)
+        const int Dm = p.qkv_d_model;
+        const int cpos = p.sp->cache_pos;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = ncol0 + i * 16;
+            if (n >= p.N) continue;
+            const int region = n / Dm, nl = n - region * Dm;  // a 4-column group never straddles a region (D % 4 == 0)
+            const floatx4 b4 = p.bias ? *reinterpret_cast<const floatx4*>(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+            const float sc = n < p.scale_n_end ? p.scale : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t m = mrow0 + j * 16 + (lane & 15);
+                if (m >= p.M) continue;
+                const floatx4 v = (acc[i][j] + b4) * sc;
+                half_t* dst = region == 0 ? reinterpret_cast<half_t*>(p.c) + m * p.ldc + nl
+                                          : (region == 1 ? p.kcache : p.vcache) + m * p.cache_row_stride + (int64_t)cpos * Dm + nl;
+                *reinterpret_cast<half4*>(dst) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             }
         }
         return;
@@ -641,6 +668,11 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     p.bias = e.bias; p.scale = e.scale; p.scale_n_end = e.scale_n_end; p.act = e.act;
     p.residual = e.residual; p.posemb = e.posemb; p.c = e.c; p.c_f32 = e.c_f32; p.ldc = e.ldc;
     p.c_rpb = e.c_rows_per_batch; p.c_brows = e.c_batch_rows; p.c_roff = e.c_row_off; p.c_packed = e.c_packed;
+    p.qkv_d_model = e.qkv_d_model; p.kcache = e.kcache; p.vcache = e.vcache; p.cache_row_stride = e.cache_row_stride; p.sp = e.sp;
+    if (e.qkv_d_model > 0)
+        WRS_REQUIRE(N == 3 * (int64_t)e.qkv_d_model && e.qkv_d_model % 64 == 0 && e.c && !e.c_f32 && !e.c_packed && e.ldc >= e.qkv_d_model && e.ldc % 4 == 0 &&
+                        e.kcache && e.vcache && e.sp && e.cache_row_stride >= e.qkv_d_model && e.ksplit <= 1 && !e.residual && !e.posemb && !e.act &&
+                        e.scale_n_end % 4 == 0, "gemm_f16: bad QKV epilogue");
     if (e.c_packed) WRS_REQUIRE(!e.c_f32 && N % 32 == 0 && e.ldc % 4 == 0, "gemm_f16: packed output needs fp16 and N %% 32 == 0");
     const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);
     p.ksplit = e.ksplit > 1 ? e.ksplit : 1;

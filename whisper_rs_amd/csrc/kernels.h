@@ -71,6 +71,14 @@ struct GemmEpi {
     int c_packed = 0;                      // fp16 output in packed-activation order (pa_off with K' = N) instead of row-major
     int ksplit = 1;                        // > 1: split-K, raw fp32 partial sums to c + slice * slab_stride (no epilogue math)
     int64_t slab_stride = 0;
+    // QKV projection of a decode step (N = 3 d_model): columns [0, D) -> c as fp16 [M, ldc] (the query, bias and scale
+    // applied), [D, 2D) / [2D, 3D) -> the new token's key / value rows of the self-attention cache at position sp->cache_pos
+    // (row m of the GEMM = physical cache row m); replaces the fp32 slab + the attention kernel's reduction of it
+    int qkv_d_model = 0;                   // > 0 selects this epilogue
+    half_t* kcache = nullptr;              // [rows][n_ctx][D]
+    half_t* vcache = nullptr;
+    int64_t cache_row_stride = 0;          // halfs between physical rows (n_ctx * D)
+    const StepParams* sp = nullptr;
 };
 struct GemmA {
     const half_t* a = nullptr;
@@ -228,8 +236,12 @@ void launch_attn_cross_q16(const half_t* q16, const half_t* kp, const half_t* vp
 // beam-de-duplicating form on the matrix cores (attn_self_mfma.hip): one wave per (audio, head) over the distinct
 // (position, physical row) pairs of the G beams' histories.  launch_self_keys builds that list once per step (it depends on
 // the ancestry table only): klist [n_audio][klist_stride >= G * n_ctx], kcount [n_audio]; phys_mul must be 1.
+// include_new: the list also holds the step's own position (one key per beam, owned by that beam): for the form of the
+// attention kernel that finds q as fp16 and the new k / v already in the cache (launch_attn_self_mfma_q16)
 void launch_self_keys(const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_audio, int G, const StepParams* sp, int* klist,
-                      int klist_stride, int* kcount, hipStream_t s);
+                      int klist_stride, int* kcount, bool include_new, hipStream_t s);
+void launch_attn_self_mfma_q16(const half_t* q16, half_t* kc, half_t* vc, int n_ctx, int n_rows, int G, int H, int D, const StepParams* sp,
+                               const int* klist, int klist_stride, const int* kcount, half_t* out, hipStream_t s);
 void launch_attn_self_mfma(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc, int n_ctx,
                            int n_rows, int G, int H, int D, const StepParams* sp, const int* klist, int klist_stride, const int* kcount,
                            half_t* out, hipStream_t s);

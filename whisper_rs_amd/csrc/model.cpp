@@ -574,9 +574,13 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
                            q_per_audio * n_ctx + 1 <= st.self_keys_stride;
     int* self_klist = st.self_keys.as<int>();
     int* self_kcount = self_klist + (size_t)st.a_cap * st.self_keys_stride;
+    // ... and at >= dec_big_gemm_rows rows the QKV GEMM's epilogue hands the attention kernel its operands directly (query as
+    // fp16, new key / value rows appended to the cache: no fp32 slab to write and re-read; WRS_DEC_QKV_SLAB=1 keeps the slab)
+    static const bool qkv_slab_forced = getenv("WRS_DEC_QKV_SLAB") && getenv("WRS_DEC_QKV_SLAB")[0] == '1';
+    const bool qkv_direct = self_mfma && big && !qkv_slab_forced;
     if (self_mfma) {
         Timed tm(timer, "dec_self_keys", stream);
-        launch_self_keys(st.anc.as<int>(), anc_stride, n_ctx, n_audio, q_per_audio, sp, self_klist, st.self_keys_stride, self_kcount, stream);
+        launch_self_keys(st.anc.as<int>(), anc_stride, n_ctx, n_audio, q_per_audio, sp, self_klist, st.self_keys_stride, self_kcount, qkv_direct, stream);
     }
     {
         Timed tm(timer, "dec_embed_ln", stream);
@@ -586,10 +590,24 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     for (int l = 0; l < L_dec; ++l) {
         const BlockW& b = dec[l];
         // x + attn(attn_ln(x))   (model.rs:302-305)
-        gemm_slab("dec_gemm_qkv", st.xn.as<half_t>(), b.qkv_w, 3 * D, D, ks_qkv, 3 * wD);
+        if (qkv_direct) {
+            Timed tm(timer, "dec_gemm_qkv", stream, 3 * wD);
+            GemmA A;
+            A.a = st.xn.as<half_t>(); A.packed = 1; A.packed_rows = st.act_rows;
+            GemmEpi e;
+            e.bias = b.qkv_b; e.scale = scale; e.scale_n_end = 2 * D; e.c = st.q16.p; e.c_f32 = 0; e.ldc = D;
+            e.qkv_d_model = D; e.kcache = st.kc.as<half_t>() + l * kv_layer; e.vcache = st.vc.as<half_t>() + l * kv_layer;
+            e.cache_row_stride = (int64_t)n_ctx * D; e.sp = sp;
+            launch_gemm_f16(A, b.qkv_w, rows, 3 * D, D, e, stream);
+        } else {
+            gemm_slab("dec_gemm_qkv", st.xn.as<half_t>(), b.qkv_w, 3 * D, D, ks_qkv, 3 * wD);
+        }
         {
             Timed tm(timer, "dec_attn_self", stream);
-            if (self_mfma)
+            if (qkv_direct)
+                launch_attn_self_mfma_q16(st.q16.as<half_t>(), st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer, n_ctx, rows,
+                                          q_per_audio, H, D, sp, self_klist, st.self_keys_stride, self_kcount, st.att.as<half_t>(), stream);
+            else if (self_mfma)
                 launch_attn_self_mfma(slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer, n_ctx,
                                       rows, q_per_audio, H, D, sp, self_klist, st.self_keys_stride, self_kcount, st.att.as<half_t>(), stream);
             else
