@@ -85,6 +85,24 @@ int main() {
             printf("mode %d %s row stride 448*2560 + %6zu: %7.1f us, %.2f TB/s (requested; distinct rows are fewer)\n", swz, swz == 1 ? "head-major" : "pos-major ", pad, best * 1e3, gb / best);
             if (pad > 0) break;
         }
+    // occupancy: the attention kernel runs at 4 waves per SIMD (124 VGPRs); limit this kernel the same way through LDS
+    {
+        extern __shared__ char dummy[];
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&walk), hipFuncAttributeMaxDynamicSharedMemorySize, 81408));
+        for (int wps : {8, 4, 3, 2})
+            for (int swz : {0, 2, 3}) {
+                const size_t lds = wps >= 8 ? 0 : 160 * 1024 / wps - 512;
+                float best = 1e9;
+                for (int rep = 0; rep < 4; ++rep) {
+                    CK(hipEventRecord(e0));
+                    walk<<<5120 / 4, 256, lds>>>(kc, vc, base, len, swz, out, list);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (rep && ms < best) best = ms;
+                }
+                printf("mode %d, %d waves per SIMD: %7.1f us, %.2f TB/s\n", swz, wps, best * 1e3, 5120.0 * len * 256 / 1e9 / best);
+            }
+    }
     // cold address translation: the decode step touches a different layer's cache (2 x 1.47 GB) at every launch, 32 layers
     // = 94 GB in rotation.  Same kernel, L regions walked round-robin; per-launch average.
     for (int L : {1, 4, 32}) {
