@@ -129,7 +129,7 @@ struct SelfMfmaParams {
 };
 
 static constexpr int SM_VIMG = 4096;              // V image: 32 keys x 128 B, 16-byte chunks XOR-swizzled with (key & 7)
-static constexpr int SM_STAGE = 2048;             // 16 rows x 128 B: q, then the new keys
+static constexpr int SM_STAGE = 4096;             // K image of the same form; before the loop: 16 rows x 128 B of staging for q, then the new keys
 static constexpr int SM_WAVE = SM_VIMG + SM_STAGE + 64;  // + 32 beam masks
 
 __device__ __forceinline__ int vimg_off(int key, int chunk) { return key * 128 + ((chunk ^ (key & 7)) << 4); }
@@ -181,16 +181,19 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
     auto entry_ok = [&](int kb, int e) -> int {
         return kb * 32 + (lane & 31) < count ? e : 0;  // 0 = (t 0, first row of the audio, no owner): a valid address, masked out
     };
+    // A load instruction covers 8 keys x 128 contiguous bytes (lane = key l >> 3, chunk l & 7): whole cache lines.  (In
+    // MFMA-fragment order — key l & 15, chunk l >> 4 — an instruction touches 16 rows for 64 bytes each and the second half
+    // of every row arrives as a separate request that hits a line with a miss pending: PMC showed the address unit stalled
+    // by the L1 70x more often than in a loads-only kernel.)  Both K and V therefore go to LDS row-major and are read back
+    // as fragments (K: ds_read_b128, V^T: ds_read_b64_tr_b16).
+    const int lkey = lane >> 3, lchunk = lane & 7;
     auto issue = [&](int e) {
 #pragma unroll
-        for (int tile = 0; tile < 2; ++tile) {
-            const int ek = __shfl(e, tile * 16 + qcol);
-            const unsigned boff = audio_b + (unsigned)((ek >> 9) & 7) * row_stride_b + (unsigned)(ek & 511) * (unsigned)(D * 2);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                kf[tile * 2 + ks] = *reinterpret_cast<const half8*>(kcb + boff + (ks * 4 + qg) * 16);
-                vf[tile * 2 + ks] = *reinterpret_cast<const half8*>(vcb + boff + (ks * 4 + qg) * 16);
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int ek = __shfl(e, i * 8 + lkey);
+            const unsigned boff = audio_b + (unsigned)((ek >> 9) & 7) * row_stride_b + (unsigned)(ek & 511) * (unsigned)(D * 2) + (unsigned)(lchunk * 16);
+            kf[i] = *reinterpret_cast<const half8*>(kcb + boff);
+            vf[i] = *reinterpret_cast<const half8*>(vcb + boff);
         }
     };
     e_nxt = entry_raw(1);
@@ -309,24 +312,32 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
         s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(knf[1], qf[1], s0, 0, 0, 0);
         block(s0, floatx4{0.f, 0.f, 0.f, 0.f});
     }
+    unsigned char* kimg = stage;  // the staging rows are dead once the loop starts
     for (int kb = 0; kb < nb; ++kb) {
-        // this block's V rows -> LDS image (the previous block's transposed reads were consumed by its MFMAs), masks
+        // this block's K and V rows -> LDS images (the previous block's reads were consumed by its MFMAs), masks
 #pragma unroll
-        for (int tile = 0; tile < 2; ++tile)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) *reinterpret_cast<half8*>(vimg + vimg_off(tile * 16 + qcol, ks * 4 + qg)) = vf[tile * 2 + ks];
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<half8*>(kimg + vimg_off(i * 8 + lkey, lchunk)) = kf[i];
+            *reinterpret_cast<half8*>(vimg + vimg_off(i * 8 + lkey, lchunk)) = vf[i];
+        }
         if (lane < 32) mbuf[lane] = (unsigned char)((e_cur >> 12) & 0xff);
-        // S^T = K Q^T (two 16-key tiles), then the next block's requests into the same registers
-        floatx4 s0 = floatx4{0.f, 0.f, 0.f, 0.f}, s1 = floatx4{0.f, 0.f, 0.f, 0.f};
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[0], s0, 0, 0, 0);
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2], qf[0], s1, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[3], qf[1], s1, 0, 0, 0);
+        // the row registers are free: the next block's requests go out before this block's arithmetic
         e_cur = entry_ok(kb + 1, e_nxt);
         if (kb + 1 < nb) {
             e_nxt = entry_raw(kb + 2);  // requested BEFORE the block's rows: waiting for it later does not wait for them
             issue(e_cur);
         }
+        // S^T = K Q^T (two 16-key tiles)
+        half8 kfr[4];
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kfr[tile * 2 + ks] = *reinterpret_cast<const half8*>(kimg + vimg_off(tile * 16 + qcol, ks * 4 + qg));
+        floatx4 s0 = floatx4{0.f, 0.f, 0.f, 0.f}, s1 = floatx4{0.f, 0.f, 0.f, 0.f};
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[0], qf[0], s0, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[1], qf[1], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[2], qf[0], s1, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[3], qf[1], s1, 0, 0, 0);
         block(s0, s1);
     }
 
