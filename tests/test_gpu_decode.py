@@ -56,7 +56,7 @@ def test_beam_search_decode_vs_oracle(gpu, dims_name, n_audio, sample_len):
 
 
 def test_beam_search_decode_with_mfma_self_attention(gpu, monkeypatch):
-    """the beam-de-duplicating MFMA self-attention (csrc/attn_self_mfma.hip: what the benchmark runs; by default from 16
+    """the beam-de-duplicating MFMA self-attention (csrc/attn_self_mfma.hip: what the benchmark runs; by default from 64
     audios per step) on a 3-audio beam-5 decode and a 2-audio beam-3 decode with a length penalty: free-running vs the oracle."""
     monkeypatch.setenv("WRS_SELF_MFMA_MIN_AUDIO", "1")  # read when a decoder state is created
     mel = mel_windows(3)

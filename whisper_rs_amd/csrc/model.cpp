@@ -473,7 +473,7 @@ void Model::init_state(DecState& st, int a_cap, int group) {
         e = getenv("WRS_DEC_FUSED");
         dec_fused_tiny = e && e[0] == '1';
         e = getenv("WRS_SELF_MFMA_MIN_AUDIO");
-        self_mfma_min_audio = e ? atoi(e) : 16;
+        self_mfma_min_audio = e ? atoi(e) : 64;
     }
     if (parity_f32) init_state_f32(st);
 }

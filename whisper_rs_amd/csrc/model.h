@@ -146,7 +146,7 @@ struct Model {
     int debug_enc_stop = 0;                 // debug: stop the encoder after N launches
     int dec_big_gemm_rows = 480;            // decode steps with at least this many rows use the tiled GEMM (env WRS_DEC_BIG_GEMM_ROWS)
     bool dec_fused_tiny = false;            // <= 16 rows, WRS_DEC_FUSED=1: finish kernels fused into the next GEMM's prologue (8 launches per layer instead of 12, but slower: DESIGN.md section 4)
-    int self_mfma_min_audio = 16;           // beam-de-duplicating MFMA self-attention from this many audios per step (WRS_SELF_MFMA_MIN_AUDIO; 0 = never)
+    int self_mfma_min_audio = 64;           // beam-de-duplicating MFMA self-attention from this many audios per step (WRS_SELF_MFMA_MIN_AUDIO; 0 = never)
     bool dec_slab_path = true;              // split-K fp32 slabs + finish kernels; WRS_DEC_PRING=1 selects the persistent-ring form (slower, see model.cpp)
     // live timing of the dominant decode kernel (cross-attention) with HIP events on this stream: every
     // `cross_ev_every`-th decode step is launched eagerly (not from the graph) with event pairs around the
