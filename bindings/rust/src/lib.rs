@@ -278,17 +278,7 @@ impl<'a> DecodeTask<'a> {
     pub fn run(&mut self, mel: &[f32]) -> anyhow::Result<Vec<DecodeOutput>> {
         let mut r = ffi::WrsDecodeResult { outputs: std::ptr::null_mut(), n_outputs: 0, n_steps: 0 };
         check(unsafe { ffi::wrs_decode_task_run(self.handle, mel.as_ptr(), 1, ffi::WRS_MEM_HOST, &mut r) })?;
-        let outs = unsafe { std::slice::from_raw_parts(r.outputs, r.n_outputs as usize) }
-            .iter()
-            .map(|o| DecodeOutput {
-                audio_features_device: o.audio_features_device,
-                tokens: unsafe { std::slice::from_raw_parts(o.tokens, o.n_tokens as usize) }.to_vec(),
-                text: unsafe { take_string(o.text) }.unwrap_or_default(),
-                avg_logprob: o.avg_logprob,
-                no_speech_prob: o.no_speech_prob,
-            })
-            .collect();
-        unsafe { ffi::wrs_decode_result_free(&mut r) };
+        let outs = collect_outputs(&mut r);
         let _ = &self.tokenizer;
         Ok(outs)
     }
@@ -300,6 +290,61 @@ impl<'a> DecodeTask<'a> {
         Ok(out)
     }
 }
+fn collect_outputs(r: &mut ffi::WrsDecodeResult) -> Vec<DecodeOutput> {
+    let outs = unsafe { std::slice::from_raw_parts(r.outputs, r.n_outputs as usize) }
+        .iter()
+        .map(|o| DecodeOutput {
+            audio_features_device: o.audio_features_device,
+            tokens: unsafe { std::slice::from_raw_parts(o.tokens, o.n_tokens as usize) }.to_vec(),
+            text: unsafe { take_string(o.text) }.unwrap_or_default(),
+            avg_logprob: o.avg_logprob,
+            no_speech_prob: o.no_speech_prob,
+        })
+        .collect();
+    unsafe { ffi::wrs_decode_result_free(r) };
+    outs
+}
+
+/// Beyond the reference (whose loop is sequential on one device): independent 30-s windows sharded over model replicas —
+/// one replica per GPU of the node, or several per GPU — each with its own worker thread and decode task pulling batches of
+/// `windows_per_batch` windows from a shared queue inside the library (no collective).  Outputs come back in window order.
+pub struct WindowPool<'a> {
+    _models: Vec<&'a Whisper>,
+    _tokenizer: Rc<Tokenizer>,
+    handle: *mut ffi::WrsWindowPool,
+}
+impl<'a> WindowPool<'a> {
+    /// `models`: one `Whisper` per worker (e.g. `Whisper::new(path, dims, gpu)` for gpu in 0..8); `options` as for `DecodeTask`
+    pub fn new(models: &[&'a Whisper], tokenizer: Rc<Tokenizer>, options: DecodeOptions, windows_per_batch: usize, overlapped: bool) -> anyhow::Result<Self> {
+        let (c, _bufs) = fill_options(&options, &tokenizer, windows_per_batch as i32)?;
+        let handles: Vec<*mut ffi::WrsModel> = models.iter().map(|m| m.handle).collect();
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { ffi::wrs_window_pool_create(handles.as_ptr(), handles.len() as i32, &tokenizer.ids, &c, overlapped as i32, &mut handle) })?;
+        check(unsafe { ffi::wrs_window_pool_set_tokenizer(handle, tokenizer.handle) })?;
+        Ok(WindowPool { _models: models.to_vec(), _tokenizer: tokenizer, handle })
+    }
+    /// `audio`: n_windows x 480 000 samples, every window its own recording (its own log-mel normalisation)
+    pub fn run_audio(&mut self, audio: &[f32]) -> anyhow::Result<Vec<DecodeOutput>> {
+        anyhow::ensure!(audio.len() % 480_000 == 0 && !audio.is_empty(), "audio must be a whole number of 30-s windows");
+        let mut r = ffi::WrsDecodeResult { outputs: std::ptr::null_mut(), n_outputs: 0, n_steps: 0 };
+        check(unsafe { ffi::wrs_window_pool_run_audio(self.handle, audio.as_ptr(), (audio.len() / 480_000) as i64, ffi::WRS_MEM_HOST, &mut r) })?;
+        Ok(collect_outputs(&mut r))
+    }
+    /// the windows of ONE recording's spectrogram [80, n_frames] (normalised over the whole file as `transcribe.rs:111-112` does),
+    /// cut at the fixed 3000-frame stride
+    pub fn run_mel(&mut self, mel: &[f32], n_frames: usize) -> anyhow::Result<Vec<DecodeOutput>> {
+        anyhow::ensure!(mel.len() == 80 * n_frames && n_frames > 0, "mel must be [80, n_frames]");
+        let mut r = ffi::WrsDecodeResult { outputs: std::ptr::null_mut(), n_outputs: 0, n_steps: 0 };
+        check(unsafe { ffi::wrs_window_pool_run_mel(self.handle, mel.as_ptr(), n_frames as i64, &mut r) })?;
+        Ok(collect_outputs(&mut r))
+    }
+}
+impl Drop for WindowPool<'_> {
+    fn drop(&mut self) {
+        unsafe { ffi::wrs_window_pool_destroy(self.handle) }
+    }
+}
+
 impl Drop for DecodeTask<'_> {
     fn drop(&mut self) {
         unsafe { ffi::wrs_decode_task_destroy(self.handle) }
