@@ -215,6 +215,8 @@ FilterCfg DecodeTask::filter_cfg() const {
     c.max_initial_ts_index = mit;
     c.suppress_ids = suppress_dev.as<int>();
     c.n_suppress = (int)suppress_ids.size();
+    c.ws = const_cast<DecState&>(st).filter_ws.as<float>();
+    c.ws_rows = std::min(st.r_cap, FILTER_SPLIT_MAX_ROWS);
     return c;
 }
 

@@ -259,7 +259,13 @@ struct FilterCfg {
     int max_initial_ts_index;   // -1: None
     const int* suppress_ids;    // device
     int n_suppress;
+    // optional workspace (device, filter_ws_floats(rows) floats): with it and few rows (<= FILTER_SPLIT_MAX_ROWS) the vocabulary
+    // of every row is split over FILTER_SPLIT workgroups + one merge wave per row (one workgroup per row leaves a 5-row step on 5 CUs)
+    float* ws = nullptr;
+    int ws_rows = 0;
 };
+constexpr int FILTER_SPLIT = 16, FILTER_SPLIT_MAX_ROWS = 64, FILTER_WS_STRIDE = 40;
+inline size_t filter_ws_floats(int rows) { return (size_t)rows * FILTER_SPLIT * FILTER_WS_STRIDE; }
 // logits [n_rows, V] f32 device.  ts_mode[r]: 0 none, 1 mask [ts_begin, V), 2 mask [0, eot)   (timestamp_tokens.rs:47-66)
 // out_lp/out_id [n_rows, k] (device-visible), no_speech [n_rows] (written when sp->want_no_speech)
 void launch_filter_topk(const float* logits, int n_rows, const FilterCfg& cfg, const StepParams* sp, const int* ts_mode,

@@ -58,6 +58,8 @@ struct FilterParams {
     int* out_id;
     float* no_speech_out;
     float* out_filtered;
+    float* ws;   // PARTIAL form: per (row, chunk) FILTER_WS_STRIDE floats: Mt St Ms Ss Mr Sr, then k (value, id) pairs text, k pairs timestamps
+    int chunk;   // PARTIAL form: columns per workgroup (multiple of 4)
 };
 
 // insertion of (cv, ci) into a list sorted by value descending, index ascending on ties (static indexing: registers)
@@ -80,6 +82,47 @@ __device__ __forceinline__ void topk_insert(float (&tv)[TOPK_MAX], int (&ti)[TOP
 // ranges the timestamp rule distinguishes — text [0, ts_begin) and timestamps [ts_begin, V) — an online (max, sum-exp)
 // pair and a per-thread top-8 list.  The rule's decision (timestamp_tokens.rs:83-96) then only picks which lists and
 // which normaliser apply; nothing has to be re-read.
+// k rounds of block arg-max over the threads' sorted lists (value descending, index ascending on ties): thread 0 emits the
+// winners through `emit(round, value, index)`
+template <typename Emit>
+__device__ __forceinline__ void block_topk(float (&tv)[TOPK_MAX], int (&ti)[TOPK_MAX], int K, float* cand_v, int* cand_i, Emit emit) {
+    const int tid = threadIdx.x;
+    int head = 0;
+    for (int round = 0; round < K; ++round) {
+        float hv = -INFINITY;
+        int hi_ = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < TOPK_MAX; ++j)
+            if (j == head) {
+                hv = tv[j];
+                hi_ = ti[j];
+            }
+        cand_v[tid] = hv;
+        cand_i[tid] = hi_;
+        __syncthreads();
+        for (int stride = 128; stride > 0; stride >>= 1) {
+            if (tid < stride) {
+                const float ov = cand_v[tid + stride];
+                const int oi = cand_i[tid + stride];
+                if (ov > cand_v[tid] || (ov == cand_v[tid] && oi < cand_i[tid])) {
+                    cand_v[tid] = ov;
+                    cand_i[tid] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        const float bv = cand_v[0];
+        const int bi = cand_i[0];
+        __syncthreads();
+        if (bi == hi_ && hi_ != 0x7fffffff) head++;
+        if (tid == 0) emit(round, bv, bi);
+    }
+}
+
+// PARTIAL: blockIdx.y = chunk of the vocabulary; the workgroup leaves its (max, sum-exp) pairs and its k best text and k best
+// timestamp candidates in the workspace, filter_merge_kernel finishes the row (few rows: one workgroup per row would use
+// rows CUs of 256).  The candidates of a row are the same set either way, so ids and their order are identical.
+template <bool PARTIAL>
 __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) {
     extern __shared__ unsigned int smem[];  // bitmask of statically suppressed ids: ceil(V/32) words
     __shared__ float red[4];
@@ -87,6 +130,8 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
     __shared__ int cand_i[256];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int V = p.n_vocab;
+    const int v_begin = PARTIAL ? (int)blockIdx.y * p.chunk : 0;
+    const int v_end = PARTIAL ? min(V, v_begin + p.chunk) : V;
     const float* x = p.logits + (int64_t)row * p.ld;
     const int first = p.sp->first_step;
     const int nwords = (V + 31) / 32;
@@ -133,20 +178,20 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
     }
     typedef float floatx4 __attribute__((ext_vector_type(4)));
     const bool vec_ok = (p.ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.logits) & 15) == 0);
-    for (int v0 = tid * 4; v0 < V; v0 += 1024) {
+    for (int v0 = v_begin + tid * 4; v0 < v_end; v0 += 1024) {
         float val4[4];
         if (vec_ok && v0 + 4 <= p.ld) {
             const floatx4 t = *reinterpret_cast<const floatx4*>(x + v0);
             val4[0] = t[0]; val4[1] = t[1]; val4[2] = t[2]; val4[3] = t[3];
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) val4[e] = v0 + e < V ? x[v0 + e] : -INFINITY;
+            for (int e = 0; e < 4; ++e) val4[e] = v0 + e < v_end ? x[v0 + e] : -INFINITY;
         }
         const unsigned bits = smem[v0 >> 5] >> (v0 & 31);  // 4 consecutive ids never straddle a 32-bit word (v0 % 4 == 0)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int v = v0 + e;
-            if (v >= V) continue;
+            if (v >= v_end) continue;
             float val = val4[e];
             if (want_ns) {  // softmax of the RAW logits (decode/mod.rs:250-255)
                 if (val > mr) { sr = sr * __expf(mr - val) + 1.f; mr = val; }
@@ -165,6 +210,20 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
         }
     }
     // ---- combine the threads' (max, sum) pairs
+    if (PARTIAL) {
+        float* w = p.ws + ((int64_t)row * gridDim.y + blockIdx.y) * FILTER_WS_STRIDE;
+        const float Mr = block_max(mr, red);
+        const float Sr = block_add(mr == -INFINITY ? 0.f : sr * __expf(mr - Mr), red);
+        const float Mt = block_max(mt, red);
+        const float St = block_add(mt == -INFINITY ? 0.f : st * __expf(mt - Mt), red);
+        const float Ms = block_max(ms, red);
+        const float Ss = block_add(ms == -INFINITY ? 0.f : ss * __expf(ms - Ms), red);
+        if (tid == 0) { w[0] = Mt; w[1] = St; w[2] = Ms; w[3] = Ss; w[4] = Mr; w[5] = Sr; }
+        const int K = p.k;
+        block_topk(tvt, tit, K, cand_v, cand_i, [&](int r, float v, int i) { w[6 + 2 * r] = v; w[7 + 2 * r] = __int_as_float(i); });
+        block_topk(tvs, tis, K, cand_v, cand_i, [&](int r, float v, int i) { w[6 + 2 * K + 2 * r] = v; w[7 + 2 * K + 2 * r] = __int_as_float(i); });
+        return;
+    }
     if (want_ns) {
         const float Mr = block_max(mr, red);
         const float Sr = block_add(mr == -INFINITY ? 0.f : sr * __expf(mr - Mr), red);
@@ -213,36 +272,75 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
         for (int j = 0; j < TOPK_MAX; ++j)
             if (tit[j] != 0x7fffffff) topk_insert(tv, ti, tvt[j], tit[j]);
     }
+    block_topk(tv, ti, p.k, cand_v, cand_i, [&](int round, float bv, int bi) {
+        p.out_lp[row * p.k + round] = (bi == 0x7fffffff) ? -INFINITY : bv - lse;
+        p.out_id[row * p.k + round] = (bi == 0x7fffffff) ? -1 : bi;
+    });
+}
+
+// second half of the split form: one wave per row merges the FILTER_SPLIT partial results exactly as the one-workgroup
+// kernel decides (timestamp_tokens.rs:83-96) and selects the k best of the chunks' candidates
+__global__ __launch_bounds__(64) void filter_merge_kernel(const FilterParams p, const int n_chunks) {
+    const int row = blockIdx.x, lane = threadIdx.x;
     const int K = p.k;
-    int head = 0;
-    for (int round = 0; round < K; ++round) {
-        float hv = -INFINITY;
-        int hi_ = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < TOPK_MAX; ++j)
-            if (j == head) {
-                hv = tv[j];
-                hi_ = ti[j];
-            }
-        cand_v[tid] = hv;
-        cand_i[tid] = hi_;
-        __syncthreads();
-        for (int stride = 128; stride > 0; stride >>= 1) {
-            if (tid < stride) {
-                const float ov = cand_v[tid + stride];
-                const int oi = cand_i[tid + stride];
-                if (ov > cand_v[tid] || (ov == cand_v[tid] && oi < cand_i[tid])) {
-                    cand_v[tid] = ov;
-                    cand_i[tid] = oi;
-                }
-            }
-            __syncthreads();
+    const float* w = p.ws + (int64_t)row * n_chunks * FILTER_WS_STRIDE;
+    const bool has = lane < n_chunks;
+    const float mt = has ? w[lane * FILTER_WS_STRIDE + 0] : -INFINITY, st = has ? w[lane * FILTER_WS_STRIDE + 1] : 0.f;
+    const float ms = has ? w[lane * FILTER_WS_STRIDE + 2] : -INFINITY, ss = has ? w[lane * FILTER_WS_STRIDE + 3] : 0.f;
+    const float mr = has ? w[lane * FILTER_WS_STRIDE + 4] : -INFINITY, sr = has ? w[lane * FILTER_WS_STRIDE + 5] : 0.f;
+    if (p.sp->want_no_speech && p.no_speech_out) {
+        const float Mr = wave_max(mr);
+        const float Sr = wave_add(mr == -INFINITY ? 0.f : sr * __expf(mr - Mr));
+        if (lane == 0) p.no_speech_out[row] = __expf(p.logits[(int64_t)row * p.ld + p.no_speech] - Mr) / Sr;
+    }
+    const float Mt = wave_max(mt);
+    const float St = wave_add(mt == -INFINITY ? 0.f : st * __expf(mt - Mt));
+    const float Ms = wave_max(ms);
+    const float Ss = wave_add(ms == -INFINITY ? 0.f : ss * __expf(ms - Ms));
+    const float mall = fmaxf(Mt, Ms);
+    const float tot = (Mt == -INFINITY ? 0.f : St * __expf(Mt - mall)) + (Ms == -INFINITY ? 0.f : Ss * __expf(Ms - mall));
+    bool mask_text = false;
+    float lse = mall + __logf(tot);
+    if (p.timestamps) {
+        const float ts_lp = (Ms == -INFINITY) ? -INFINITY : (Ms - lse) + __logf(Ss);
+        const float text_lp = Mt - lse;
+        if (ts_lp > text_lp) {
+            mask_text = true;
+            lse = Ms + __logf(Ss);
         }
-        const float bv = cand_v[0];
-        const int bi = cand_i[0];
-        __syncthreads();
-        if (bi == hi_ && hi_ != 0x7fffffff) head++;
-        if (tid == 0) {
+    }
+    // candidates: n_chunks * K text + n_chunks * K timestamp entries, 4 per lane (n_chunks * K * 2 <= 256)
+    float cv[4];
+    int ci[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = lane + 64 * j;
+        cv[j] = -INFINITY;
+        ci[j] = 0x7fffffff;
+        if (e < 2 * n_chunks * K) {
+            const int list = e / (n_chunks * K), rem = e % (n_chunks * K);  // 0: text, 1: timestamps
+            const int c = rem / K, r = rem % K;
+            const float* q = w + c * FILTER_WS_STRIDE + 6 + list * 2 * K + 2 * r;
+            const int idx = __float_as_int(q[1]);
+            if (idx != 0x7fffffff && !(list == 0 && mask_text)) { cv[j] = q[0]; ci[j] = idx; }
+        }
+    }
+    for (int round = 0; round < K; ++round) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (cv[j] > bv || (cv[j] == bv && ci[j] < bi)) { bv = cv[j]; bi = ci[j]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ci[j] == bi && bi != 0x7fffffff) { cv[j] = -INFINITY; ci[j] = 0x7fffffff; }
+        if (lane == 0) {
             p.out_lp[row * K + round] = (bi == 0x7fffffff) ? -INFINITY : bv - lse;
             p.out_id[row * K + round] = (bi == 0x7fffffff) ? -1 : bi;
         }
@@ -289,7 +387,17 @@ void launch_filter_topk(const float* logits, int n_rows, const FilterCfg& cfg, c
     p.suppress_ids = cfg.suppress_ids; p.n_suppress = cfg.n_suppress; p.sp = sp; p.ts_mode = ts_mode; p.k = k;
     p.out_lp = out_lp; p.out_id = out_id; p.no_speech_out = no_speech; p.out_filtered = out_filtered;
     const size_t shmem = (size_t)((cfg.n_vocab + 31) / 32) * 4;
-    filter_topk_kernel<<<n_rows, 256, shmem, s>>>(p);
+    p.ws = nullptr; p.chunk = 0;
+    static const bool split_off = getenv("WRS_FILTER_SPLIT") && getenv("WRS_FILTER_SPLIT")[0] == '0';
+    if (cfg.ws && !out_filtered && !split_off && n_rows <= FILTER_SPLIT_MAX_ROWS && n_rows <= cfg.ws_rows && 2 * FILTER_SPLIT * k <= 256 &&
+        6 + 4 * k <= FILTER_WS_STRIDE) {
+        p.ws = cfg.ws;
+        p.chunk = (int)round_up(cdiv(cfg.n_vocab, FILTER_SPLIT), 4);
+        filter_topk_kernel<true><<<dim3((unsigned)n_rows, FILTER_SPLIT), 256, shmem, s>>>(p);
+        filter_merge_kernel<<<n_rows, 64, 0, s>>>(p, FILTER_SPLIT);
+        return;
+    }
+    filter_topk_kernel<false><<<n_rows, 256, shmem, s>>>(p);
 }
 
 }  // namespace wrs

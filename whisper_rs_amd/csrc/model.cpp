@@ -462,6 +462,7 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.sp_dev.alloc(st.sp_bytes());
     st.sp_host.alloc(st.sp_bytes());
     st.topk.alloc((size_t)r_cap * 17 * 4);
+    st.filter_ws.alloc(filter_ws_floats(std::min(r_cap, FILTER_SPLIT_MAX_ROWS)) * 4);
     st.len = 0;
     st.parity = 0;
     st.n_audio = 0;

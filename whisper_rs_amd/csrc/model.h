@@ -69,6 +69,7 @@ struct DecState {
     half_t* cvp(int sel) const { return (sel ? cross_vp2 : cross_vp).as<half_t>(); }
     DevBuf kc, vc;              // [L][r_cap][n_ctx][D]
     DevBuf anc;                 // [2][r_cap][n_ctx]
+    DevBuf filter_ws;           // partial results of the split filter / top-k (kernels.h filter_ws_floats), few-row steps
     DevBuf self_keys;           // [a_cap][G * n_ctx] distinct (position, row) pairs of every audio's beams + [a_cap] counts (attn_self_mfma.hip)
     int self_keys_stride = 0;
     DevBuf x, xn, att, h, slab, logits, ckv_tmp;
