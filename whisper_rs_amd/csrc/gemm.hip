@@ -535,16 +535,16 @@ __global__ __launch_bounds__(64 * (NC + NL)) void gemm_f16_ring_kernel(const Gem
 // Activation tile: 256 rows x 64 B; a piece is 16 rows x 64 B (lane -> row l/4, chunk l%4).  Fragment reads take chunk
 // l>>4 of rows l&15: the chunk position is XOR-swizzled with (row >> 2) & 3 (on the source address of the request, the
 // LDS destination of a direct-to-LDS load being lane-linear) so the 16 lanes of a read group hit 64 distinct banks.
-__global__ __launch_bounds__(512) void gemm_f16_pp2_kernel(const GemmParams p) {
+// one 256x256 tile (number `seq` of the XCD-aware sequence, k-slice `kslice`) by the 8 waves of a workgroup
+__device__ __forceinline__ void pp2_tile(const GemmParams& p, const int seq, const int kslice, half8* smem) {
     constexpr int STAGE = 2048;  // half8 units per ring slot: activations 256 x 64 B (1024) + weights 16 fragments (1024)
-    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
-    half8* smem = reinterpret_cast<half8*>(gemm_smem);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int tid = threadIdx.x;
+    // opaque to the optimiser: inside a tile LOOP (scripts/micro/cu_confine.h) it would otherwise hoist every lane-dependent
+    // address term out of the loop and keep it in registers across the tile (213 -> 256 VGPRs + 124 B of scratch per lane)
+    asm volatile("" : "+v"(tid));
+    const int wave = tid >> 6, lane = tid & 63;
     const int grp = wave >> 2, w4 = wave & 3;
     const int mt_n = (p.M + 255) >> 8, nt_n = p.N >> 8;
-    const int tiles = mt_n * nt_n, per_xcd = (tiles + 7) >> 3;
-    const int seq = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (seq >= tiles) return;  // whole workgroup, before any barrier
     const int band = seq / (8 * nt_n);
     const int band_m0 = band * 8;
     const int band_rows = min(8, mt_n - band_m0);
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp2_kernel(const GemmParams p) {
         w_ptr[j] = p.wp + ((int64_t)(n0 / 16 + f) * p.ksteps) * 512 + lane * 8;
     }
     const int nk = p.K / 32 / p.ksplit;
-    const int kt0 = blockIdx.y * nk;
+    const int kt0 = kslice * nk;
 #define WRS_PP2_ISSUE(u_)                                                                                                      \
     do {                                                                                                                       \
         half8* st_ = smem + ((u_) & 3) * STAGE;                                                                                \
@@ -646,6 +646,15 @@ __global__ __launch_bounds__(512) void gemm_f16_pp2_kernel(const GemmParams p) {
     const int64_t mrow = (int64_t)m0 + grp * 128 + wx * 64;
     gemm_epilogue(p, acc0, mrow, n0 + wy * 128, lane);
     gemm_epilogue(p, acc1, mrow, n0 + wy * 128 + 64, lane);
+}
+
+__global__ __launch_bounds__(512) void gemm_f16_pp2_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+    const int mt_n = (p.M + 255) >> 8, nt_n = p.N >> 8;
+    const int tiles = mt_n * nt_n, per_xcd = (tiles + 7) >> 3;
+    const int seq = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (seq >= tiles) return;  // whole workgroup, before any barrier
+    pp2_tile(p, seq, blockIdx.y, reinterpret_cast<half8*>(gemm_smem));
 }
 
 static int gemm_pp2_min_wgs = 256;

@@ -431,6 +431,18 @@ void Model::encoder_from_mel_t(int n) {
 }
 
 // ------------------------------------------------------------------------------------------ decoder
+// Experiment switches (unset = the default path).  Read ONCE per model, at creation: a decode task's captured step graph is keyed
+// on (rows, cross buffer) only, so a switch that changed under a live model would leave graph and eager steps on different paths.
+void Model::read_switches() {
+    if (const char* e = getenv("WRS_DEC_BIG_GEMM_ROWS")) dec_big_gemm_rows = atoi(e);
+    const char* e = getenv("WRS_DEC_PRING");
+    dec_slab_path = !(e && e[0] == '1');
+    e = getenv("WRS_DEC_FUSED");
+    dec_fused_tiny = e && e[0] == '1';
+    e = getenv("WRS_SELF_MFMA_MIN_AUDIO");
+    self_mfma_min_audio = e ? atoi(e) : 64;
+}
+
 void Model::init_state(DecState& st, int a_cap, int group) {
     WRS_REQUIRE(finalized, "model not finalized");
     WRS_REQUIRE(a_cap >= 1 && group >= 1 && group <= 16, "decoder state: bad capacity (audios %d, group %d)", a_cap, group);
@@ -467,15 +479,6 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     st.parity = 0;
     st.n_audio = 0;
     st.pending_src.clear();
-    if (const char* e = getenv("WRS_DEC_BIG_GEMM_ROWS")) dec_big_gemm_rows = atoi(e);
-    {   // experiment switches, re-read for every decoder state (unset = the default path)
-        const char* e = getenv("WRS_DEC_PRING");
-        dec_slab_path = !(e && e[0] == '1');
-        e = getenv("WRS_DEC_FUSED");
-        dec_fused_tiny = e && e[0] == '1';
-        e = getenv("WRS_SELF_MFMA_MIN_AUDIO");
-        self_mfma_min_audio = e ? atoi(e) : 64;
-    }
     if (parity_f32) init_state_f32(st);
 }
 
