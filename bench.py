@@ -238,7 +238,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v2")
-    ap.add_argument("--batch", type=int, default=256, help="30-s windows per step per GPU (independent units; 256 x beam 5 = 1280 decoder rows)")
+    ap.add_argument("--batch", type=int, default=307, help="30-s windows per step per GPU (independent units; 307 x beam 5 = 1535 decoder rows = 12 row tiles of 128: the "
+                    "largest batch whose decode GEMMs still fit one round of workgroups — 480 MLP-1 tiles on 512 slots; 320 windows take two rounds and lose 5 %)")
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--sample-len", type=int, default=224)
     ap.add_argument("--lanes", type=int, default=1, help="model replicas per GPU, each decoding its own batches from its own worker thread (wrs_window_pool); "

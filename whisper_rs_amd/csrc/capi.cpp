@@ -113,7 +113,7 @@ int wrs_decoder_forward(wrs_model* h, const int64_t* tokens, int n_batch, int n_
         }
         WRS_REQUIRE(st.n_audio >= n_batch, "wrs_decoder_forward: xa is NULL but no cross-attention K/V are cached for %d rows", n_batch);
         if (st.len == 0) {
-            launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m.n_ctx, m.n_ctx, st.r_cap, 1, m.stream);
+            launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * st.ctx, st.ctx, st.r_cap, 1, m.stream);
             st.parity = 0;
         }
         WRS_REQUIRE(st.len + n_tokens <= m.n_ctx && offset + n_tokens <= m.n_ctx, "wrs_decoder_forward: %d cached + %d new tokens (offset %ld) exceed n_text_ctxs %d",

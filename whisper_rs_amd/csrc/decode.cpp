@@ -150,10 +150,22 @@ void DecodeTask::configure(Model* model, const wrs_token_ids& tid, const wrs_dec
         WRS_REQUIRE(o.sot_sequence_tail && o.sot_sequence_tail[i] >= 0 && o.sot_sequence_tail[i] < V, "DecodeTask: sot sequence token out of range");
         sot_tail.push_back(o.sot_sequence_tail[i]);
     }
-    m->init_state(st, max_audio, group);
     set_prompt(nullptr, 0);
+    // K/V cache positions by need (prompt + sample_len), grown by ensure_ctx when a longer prompt is set: at large-v2 and 1 535
+    // rows all 448 positions would take 113 GB
+    m->init_state(st, max_audio, group, ctx_for(sample_begin + sample_len));
     const char* env = getenv("WRS_NO_GRAPH");
     use_graph = !(env && env[0] == '1');
+}
+
+int DecodeTask::ctx_for(int positions) const { return (int)std::min<int64_t>(m->n_ctx, round_up(std::max(positions, 1), 32)); }
+// the self-attention cache must hold `positions` tokens per row: grow it (contents lost: between runs only) and drop the step graph
+void DecodeTask::ensure_ctx(int positions) {
+    if (std::min(positions, m->n_ctx) <= st.ctx) return;
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    m->resize_ctx(st, m->n_ctx);  // a prompt outgrew the initial size (long-form conditioning keeps growing it): all positions, once
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    graph_rows = -1;
 }
 
 void DecodeTask::set_prompt(const int64_t* p, int n) {  // decode/mod.rs:46-92,206-218
@@ -189,7 +201,7 @@ void DecodeTask::detect_language(int n_audio, int first_id, int n_lang, int32_t*
     m->use();
     hipStream_t s = m->stream;
     m->load_cross_kv(st, m->enc_ws.xa16.as<half_t>(), n_audio);
-    launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m->n_ctx, m->n_ctx, st.r_cap, group, s);
+    launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * st.ctx, st.ctx, st.r_cap, group, s);
     StepParams* sp = st.sp_h();
     sp->cache_pos = 0; sp->pos_idx = 0; sp->parity = 0; sp->first_step = 1; sp->want_no_speech = 0; sp->n_rows = n_audio;
     for (int a = 0; a < n_audio; ++a) { st.tokens_h()[a] = ids.sot; st.src_h()[a] = a; st.tsmode_h()[a] = 0; }
@@ -513,7 +525,8 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
     const int G = group, R = n_audio * G, S = sample_begin;
     WRS_REQUIRE(S <= m->n_ctx, "prompt of %d tokens exceeds n_text_ctxs %d (the reference panics slicing positional_embedding)", S, m->n_ctx);
     hipStream_t s = m->stream;
-    launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m->n_ctx, m->n_ctx, st.r_cap, G, s);
+    ensure_ctx(S + sample_len);
+    launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * st.ctx, st.ctx, st.r_cap, G, s);
     t_prefill_ms = t_steps_ms = t_host_ms = 0;
     double tA = now_ms();
 
@@ -556,7 +569,7 @@ void DecodeTask::run_decode(int n_audio, wrs_decode_result* out) {
         StepParams* sp = st.sp_h();
         sp->cache_pos = S + i - 1;
         sp->pos_idx = position_quirk ? i : S + i - 1;
-        WRS_REQUIRE(sp->pos_idx < m->n_ctx && sp->cache_pos < m->n_ctx, "decode: position %d out of range", sp->cache_pos);
+        WRS_REQUIRE(sp->pos_idx < m->n_ctx && sp->cache_pos < st.ctx, "decode: position %d out of range (cache holds %d)", sp->cache_pos, st.ctx);
         sp->parity = i & 1; sp->first_step = 0; sp->want_no_speech = 0; sp->n_rows = R;
         for (int r = 0; r < R; ++r) {
             st.tokens_h()[r] = (int)seqs.back(rows[r]);
@@ -642,8 +655,9 @@ void DecodeTask::run_forced(int n_audio, int n_steps, const int32_t* ftok, const
     const int k = (mode == WRS_EXTRACT_BEAM_SEARCH) ? G + 1 : 1;
     WRS_REQUIRE(S + n_steps - 1 <= m->n_ctx, "run_forced: %d prompt + %d steps exceed n_text_ctxs", S, n_steps);
     hipStream_t s = m->stream;
+    ensure_ctx(S + n_steps);
     m->load_cross_kv(st, m->enc_ws.xa16.as<half_t>(), n_audio);
-    launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * m->n_ctx, m->n_ctx, st.r_cap, G, s);
+    launch_anc_init(st.anc.as<int>(), (int64_t)st.r_cap * st.ctx, st.ctx, st.r_cap, G, s);
     const FilterCfg cfg = filter_cfg();
     {
         const int keep = sample_len;

@@ -120,6 +120,8 @@ struct DecodeTask {
     bool use_graph = true;
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;
+    int ctx_for(int positions) const;  // cache positions to allocate for `positions` tokens per row
+    void ensure_ctx(int positions);
     int graph_rows = -1, graph_sel = -1;  // the captured step reads the cross K/V buffer `graph_sel`
 
     // overlapped mode: mel + encoder + cross-K/V projection of up to two window batches queued on a side stream

@@ -443,7 +443,7 @@ void Model::read_switches() {
     self_mfma_min_audio = e ? atoi(e) : 64;
 }
 
-void Model::init_state(DecState& st, int a_cap, int group) {
+void Model::init_state(DecState& st, int a_cap, int group, int ctx) {
     WRS_REQUIRE(finalized, "model not finalized");
     WRS_REQUIRE(a_cap >= 1 && group >= 1 && group <= 16, "decoder state: bad capacity (audios %d, group %d)", a_cap, group);
     const int r_cap = a_cap * group;
@@ -454,11 +454,7 @@ void Model::init_state(DecState& st, int a_cap, int group) {
     const size_t per_head = packed_kv_halfs_per_head(T);
     st.cross_kp.alloc((size_t)L_dec * a_cap * H * per_head * 2);
     st.cross_vp.alloc((size_t)L_dec * a_cap * H * per_head * 2);
-    st.kc.alloc((size_t)L_dec * r_cap * n_ctx * D * 2);
-    st.vc.alloc((size_t)L_dec * r_cap * n_ctx * D * 2);
-    st.anc.alloc((size_t)2 * r_cap * n_ctx * 4);
-    st.self_keys_stride = (r_cap / std::max(a_cap, 1)) * n_ctx + 1;  // [0] = count
-    st.self_keys.alloc(((size_t)a_cap * st.self_keys_stride + a_cap) * 4);
+    resize_ctx(st, ctx > 0 ? std::min(ctx, n_ctx) : n_ctx);
     st.act_rows = (int)round_up(m_pad, 128);  // packed activations are also read in 128-row tiles by the big GEMM
     st.x.alloc((size_t)m_pad * D * 4);
     st.xn.alloc((size_t)st.act_rows * D * 2);
@@ -507,6 +503,26 @@ void Model::load_cross_kv(DecState& st, const half_t* xa16, int n_audio) {
     st.n_audio = n_audio;
 }
 
+// The self-attention K/V cache, the ancestry table and the key lists hold `ctx` positions per row (<= n_text_ctxs): a decode
+// task sizes them by what its prompt and sample_len can reach (large-v2, 1 535 rows: 58 GB for 256 positions against 113 GB for
+// all 448) and grows them when a longer prompt arrives.  Contents are lost: call between runs only.
+void Model::resize_ctx(DecState& st, int ctx) {
+    WRS_REQUIRE(ctx >= 1 && ctx <= n_ctx && st.r_cap >= 1, "decoder state: %d cache positions not in 1..%d", ctx, n_ctx);
+    use();
+    st.kc.release(); st.vc.release();  // before the new allocation: both sizes together may not fit
+    st.ctx = ctx;
+    st.kc.alloc((size_t)L_dec * st.r_cap * ctx * D * 2);
+    st.vc.alloc((size_t)L_dec * st.r_cap * ctx * D * 2);
+    st.anc.alloc((size_t)2 * st.r_cap * ctx * 4);
+    st.self_keys_stride = (st.r_cap / std::max(st.a_cap, 1)) * ctx + 1;  // [0] = count
+    st.self_keys.alloc(((size_t)st.a_cap * st.self_keys_stride + st.a_cap) * 4);
+    if (st.f32) {  // f32 parity mode: its fp32 caches follow
+        st.f32->kc.alloc((size_t)L_dec * st.r_cap * ctx * D * 4);
+        st.f32->vc.alloc((size_t)L_dec * st.r_cap * ctx * D * 4);
+    }
+    st.len = 0;
+}
+
 // split-K factor of a decode GEMM: enough workgroups (N/32 * ksplit >= ~200) to spread the weight stream over
 // the 256 CUs, at most 10 k-steps per wave (gemm.hip SK_NKS) and at least 4 k-steps per workgroup.  The total
 // activation traffic of a GEMM does not depend on ksplit (every workgroup reads only its k-slice of A), so
@@ -527,8 +543,8 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     if (parity_f32) { decoder_step_f32(st, rows, phys_mul, q_per_audio, update_anc, want_logits); return; }
     const float scale = std::pow((float)(D / H), -0.25f);
     const StepParams* sp = st.sp_d();
-    const int64_t anc_stride = (int64_t)st.r_cap * n_ctx;
-    const size_t kv_layer = (size_t)st.r_cap * n_ctx * D;
+    const int64_t anc_stride = (int64_t)st.r_cap * st.ctx;
+    const size_t kv_layer = (size_t)st.r_cap * st.ctx * D;
     const size_t cross_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
     const int n_audio = rows / q_per_audio;
     const double wD = (double)D * D * 2;  // bytes of a [D, D] fp16 matrix
@@ -570,12 +586,12 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     }
     if (update_anc) {
         Timed tm(timer, "dec_anc_update", stream);
-        launch_anc_update(st.anc.as<int>(), anc_stride, n_ctx, rows, sp, st.src_d(), stream);
+        launch_anc_update(st.anc.as<int>(), anc_stride, st.ctx, rows, sp, st.src_d(), stream);
     }
     // many audios with several beams each: self-attention over the DISTINCT (position, row) pairs of an audio's beams, on
     // the matrix cores (attn_self_mfma.hip); the pair list follows from the ancestry table, once per step for all layers
     const bool self_mfma = self_mfma_min_audio > 0 && phys_mul == 1 && q_per_audio >= 2 && q_per_audio <= 8 && n_audio >= self_mfma_min_audio &&
-                           q_per_audio * n_ctx + 1 <= st.self_keys_stride;
+                           q_per_audio * st.ctx + 1 <= st.self_keys_stride;
     int* self_klist = st.self_keys.as<int>();
     int* self_kcount = self_klist + (size_t)st.a_cap * st.self_keys_stride;
     // ... and at >= dec_big_gemm_rows rows the QKV GEMM's epilogue hands the attention kernel its operands directly (query as
@@ -584,7 +600,7 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     const bool qkv_direct = self_mfma && big && !qkv_slab_forced;
     if (self_mfma) {
         Timed tm(timer, "dec_self_keys", stream);
-        launch_self_keys(st.anc.as<int>(), anc_stride, n_ctx, n_audio, q_per_audio, sp, self_klist, st.self_keys_stride, self_kcount, qkv_direct, stream);
+        launch_self_keys(st.anc.as<int>(), anc_stride, st.ctx, n_audio, q_per_audio, sp, self_klist, st.self_keys_stride, self_kcount, qkv_direct, stream);
     }
     {
         Timed tm(timer, "dec_embed_ln", stream);
@@ -601,7 +617,7 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
             GemmEpi e;
             e.bias = b.qkv_b; e.scale = scale; e.scale_n_end = 2 * D; e.c = st.q16.p; e.c_f32 = 0; e.ldc = D;
             e.qkv_d_model = D; e.kcache = st.kc.as<half_t>() + l * kv_layer; e.vcache = st.vc.as<half_t>() + l * kv_layer;
-            e.cache_row_stride = (int64_t)n_ctx * D; e.sp = sp;
+            e.cache_row_stride = (int64_t)st.ctx * D; e.sp = sp;
             launch_gemm_f16(A, b.qkv_w, rows, 3 * D, D, e, stream);
         } else {
             gemm_slab("dec_gemm_qkv", st.xn.as<half_t>(), b.qkv_w, 3 * D, D, ks_qkv, 3 * wD);
@@ -609,14 +625,14 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
         {
             Timed tm(timer, "dec_attn_self", stream);
             if (qkv_direct)
-                launch_attn_self_mfma_q16(st.q16.as<half_t>(), st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer, n_ctx, rows,
+                launch_attn_self_mfma_q16(st.q16.as<half_t>(), st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer, st.ctx, rows,
                                           q_per_audio, H, D, sp, self_klist, st.self_keys_stride, self_kcount, st.att.as<half_t>(), stream);
             else if (self_mfma)
-                launch_attn_self_mfma(slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer, n_ctx,
+                launch_attn_self_mfma(slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer, st.ctx,
                                       rows, q_per_audio, H, D, sp, self_klist, st.self_keys_stride, self_kcount, st.att.as<half_t>(), stream);
             else
                 launch_attn_self(slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer,
-                                 st.anc.as<int>(), anc_stride, n_ctx, rows, q_per_audio, phys_mul, H, D, sp, st.att.as<half_t>(), stream);
+                                 st.anc.as<int>(), anc_stride, st.ctx, rows, q_per_audio, phys_mul, H, D, sp, st.att.as<half_t>(), stream);
         }
         gemm_slab("dec_gemm_out", st.att.as<half_t>(), b.out_w, D, D, ks_d, wD);
         {
@@ -676,8 +692,8 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
 void Model::decoder_step_tiny(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits) {
     const float scale = std::pow((float)(D / H), -0.25f);
     const StepParams* sp = st.sp_d();
-    const int64_t anc_stride = (int64_t)st.r_cap * n_ctx;
-    const size_t kv_layer = (size_t)st.r_cap * n_ctx * D;
+    const int64_t anc_stride = (int64_t)st.r_cap * st.ctx;
+    const size_t kv_layer = (size_t)st.r_cap * st.ctx * D;
     const size_t cross_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
     const int n_audio = rows / q_per_audio;
     const int mp = 16;
@@ -688,7 +704,7 @@ void Model::decoder_step_tiny(DecState& st, int rows, int phys_mul, int q_per_au
     half_t* att = st.att.as<half_t>();
     if (update_anc) {
         Timed tm(timer, "dec_anc_update", stream);
-        launch_anc_update(st.anc.as<int>(), anc_stride, n_ctx, rows, sp, st.src_d(), stream);
+        launch_anc_update(st.anc.as<int>(), anc_stride, st.ctx, rows, sp, st.src_d(), stream);
     }
     {
         Timed tm(timer, "dec_embed_ln", stream);
@@ -721,7 +737,7 @@ void Model::decoder_step_tiny(DecState& st, int rows, int phys_mul, int q_per_au
         {
             Timed tm(timer, "dec_attn_self", stream);
             launch_attn_self(pend_slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer,
-                             st.anc.as<int>(), anc_stride, n_ctx, rows, q_per_audio, phys_mul, H, D, sp, att, stream);
+                             st.anc.as<int>(), anc_stride, st.ctx, rows, q_per_audio, phys_mul, H, D, sp, att, stream);
         }
         pend_ks = plain("dec_gemm_out", att, b.out_w, D, np_d, D);
         pend_bias = b.out_b;
@@ -761,8 +777,8 @@ void Model::decoder_step_tiny(DecState& st, int rows, int phys_mul, int q_per_au
 void Model::decoder_step_big(DecState& st, int rows, int phys_mul, int q_per_audio, bool update_anc, bool want_logits) {
     const float scale = std::pow((float)(D / H), -0.25f);
     const StepParams* sp = st.sp_d();
-    const int64_t anc_stride = (int64_t)st.r_cap * n_ctx;
-    const size_t kv_layer = (size_t)st.r_cap * n_ctx * D;
+    const int64_t anc_stride = (int64_t)st.r_cap * st.ctx;
+    const size_t kv_layer = (size_t)st.r_cap * st.ctx * D;
     const size_t cross_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
     const int n_audio = rows / q_per_audio;
     const double wD = (double)D * D * 2;
@@ -782,7 +798,7 @@ void Model::decoder_step_big(DecState& st, int rows, int phys_mul, int q_per_aud
     };
     if (update_anc) {
         Timed tm(timer, "dec_anc_update", stream);
-        launch_anc_update(st.anc.as<int>(), anc_stride, n_ctx, rows, sp, st.src_d(), stream);
+        launch_anc_update(st.anc.as<int>(), anc_stride, st.ctx, rows, sp, st.src_d(), stream);
     }
     {
         Timed tm(timer, "dec_embed_ln", stream);
@@ -796,12 +812,12 @@ void Model::decoder_step_big(DecState& st, int rows, int phys_mul, int q_per_aud
             Timed tm(timer, "dec_gemm_qkv", stream, 3 * wD);
             PringEpi e;
             e.mode = PRING_QKV; e.bias = b.qkv_b; e.scale = scale; e.scale_n_end = 2 * D; e.c16 = q16; e.ldc = D;
-            e.kcache = kc; e.vcache = vc; e.d_model = D; e.cache_row_stride = (int64_t)n_ctx * D; e.phys_mul = phys_mul; e.sp = sp;
+            e.kcache = kc; e.vcache = vc; e.d_model = D; e.cache_row_stride = (int64_t)st.ctx * D; e.phys_mul = phys_mul; e.sp = sp;
             launch_gemm_pring(xn, st.act_rows, b.qkv_w, rows, 3 * D, D, 128, e, stream);
         }
         {
             Timed tm(timer, "dec_attn_self", stream);
-            launch_attn_self_q16(q16, kc, vc, st.anc.as<int>(), anc_stride, n_ctx, rows, q_per_audio, phys_mul, H, D, sp, att, stream);
+            launch_attn_self_q16(q16, kc, vc, st.anc.as<int>(), anc_stride, st.ctx, rows, q_per_audio, phys_mul, H, D, sp, att, stream);
         }
         resid("dec_gemm_out", att, b.out_w, b.out_b, D, wD);
         ln(b.cross_ln_g, b.cross_ln_b);
@@ -860,7 +876,7 @@ void Model::decoder_logits(DecState& st, int rows) {
 void Model::decoder_prefill(DecState& st, int n_audio, int S, int pos0, int phys_mul, const int* tokens_host, bool all_logits) {
     WRS_REQUIRE(finalized && !parity_f32, "decoder_prefill: not available in this mode");
     check_device("decoder prefill");
-    WRS_REQUIRE(n_audio >= 1 && n_audio <= st.n_audio && S >= 1 && pos0 >= 0 && pos0 + S <= n_ctx, "decoder_prefill: bad shape (%d audios, %d tokens at %d)", n_audio, S, pos0);
+    WRS_REQUIRE(n_audio >= 1 && n_audio <= st.n_audio && S >= 1 && pos0 >= 0 && pos0 + S <= st.ctx, "decoder_prefill: bad shape (%d audios, %d tokens at %d)", n_audio, S, pos0);
     WRS_REQUIRE((int64_t)(n_audio - 1) * phys_mul < st.r_cap, "decoder_prefill: physical row out of range");
     WRS_REQUIRE(pos0 == 0, "decoder_prefill: a non-empty cache is not supported (causal attention over cached + new positions)");
     PrefillWorkspace& w = st.prefill;
@@ -881,7 +897,7 @@ void Model::decoder_prefill(DecState& st, int n_audio, int S, int pos0, int phys
     }
     if (all_logits) w.logits_all.ensure((size_t)M * st.logits_ld * 4);
     const float scale = std::pow((float)(D / H), -0.25f);
-    const size_t kv_layer = (size_t)st.r_cap * n_ctx * D;
+    const size_t kv_layer = (size_t)st.r_cap * st.ctx * D;
     const size_t cross_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
     HIP_CHECK(hipMemcpyAsync(w.tokens.p, tokens_host, (size_t)M * 4, hipMemcpyHostToDevice, stream));
     float* x = w.x.as<float>();
@@ -900,7 +916,7 @@ void Model::decoder_prefill(DecState& st, int n_audio, int S, int pos0, int phys
         }
         {
             Timed tm(timer, "pre_attn_self", stream);
-            launch_prefill_store_kv(w.qkv.as<half_t>(), n_audio, S, pos0, D, n_ctx, phys_mul, st.kc.as<half_t>() + l * kv_layer,
+            launch_prefill_store_kv(w.qkv.as<half_t>(), n_audio, S, pos0, D, st.ctx, phys_mul, st.kc.as<half_t>() + l * kv_layer,
                                     st.vc.as<half_t>() + l * kv_layer, stream);
             launch_pack_kv(w.qkv.as<half_t>(), 3 * D, D, 2 * D, n_audio, S, H, w.kp.as<half_t>(), w.vp.as<half_t>(), stream);
             launch_attn_full(w.qkv.as<half_t>(), 3 * D, w.kp.as<half_t>(), w.vp.as<half_t>(), n_audio, S, S, H, w.att.as<half_t>(), D, stream, true);

@@ -58,6 +58,7 @@ struct PrefillWorkspace {
 // decoder K/V caches + per-step scratch for up to `a_cap` audios x `group` rows
 struct DecState {
     int a_cap = 0, group = 1, r_cap = 0, m_pad = 0, act_rows = 0, logits_ld = 0;
+    int ctx = 0;      // positions per row of kc / vc / anc / self_keys (<= the model's n_text_ctxs; Model::resize_ctx)
     int n_audio = 0;  // audios whose cross K/V are loaded
     DevBuf cross_kp, cross_vp;  // [L][a_cap][H][Tp*64]
     // second cross-attention K/V buffer (allocated on first use by the overlapped mode: the next window batch's encoder
@@ -67,8 +68,8 @@ struct DecState {
     int cross_wsel = 0;  // buffer load_cross_kv writes
     half_t* ckp(int sel) const { return (sel ? cross_kp2 : cross_kp).as<half_t>(); }
     half_t* cvp(int sel) const { return (sel ? cross_vp2 : cross_vp).as<half_t>(); }
-    DevBuf kc, vc;              // [L][r_cap][n_ctx][D]
-    DevBuf anc;                 // [2][r_cap][n_ctx]
+    DevBuf kc, vc;              // [L][r_cap][ctx][D]
+    DevBuf anc;                 // [2][r_cap][ctx]
     DevBuf filter_ws;           // partial results of the split filter / top-k (kernels.h filter_ws_floats), few-row steps
     DevBuf self_keys;           // [a_cap][G * n_ctx] distinct (position, row) pairs of every audio's beams + [a_cap] counts (attn_self_mfma.hip)
     int self_keys_stride = 0;
@@ -179,7 +180,8 @@ struct Model {
     void load_mel_window(const float* mel_dev, int64_t n_frames, int64_t seek, int slot);
 
     // decoder
-    void init_state(DecState& st, int a_cap, int group);
+    void init_state(DecState& st, int a_cap, int group, int ctx = 0);  // ctx: cache positions per row (0 = n_text_ctxs)
+    void resize_ctx(DecState& st, int ctx);
     // cross-attention K/V for `n_audio` audios from xa16 [n_audio*T, D] fp16 (device)
     void load_cross_kv(DecState& st, const half_t* xa16, int n_audio);
     // one token per row. rows = logical rows this step; phys_mul = physical cache-row stride per logical row;

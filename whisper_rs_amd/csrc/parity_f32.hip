@@ -288,8 +288,8 @@ void Model::init_state_f32(DecState& st) {
     st.f32.reset(new DecStateF32());
     DecStateF32& f = *st.f32;
     f.cross.alloc((size_t)L_dec * st.a_cap * T * 2 * D * 4);
-    f.kc.alloc((size_t)L_dec * st.r_cap * n_ctx * D * 4);
-    f.vc.alloc((size_t)L_dec * st.r_cap * n_ctx * D * 4);
+    f.kc.alloc((size_t)L_dec * st.r_cap * st.ctx * D * 4);
+    f.vc.alloc((size_t)L_dec * st.r_cap * st.ctx * D * 4);
     f.xn.alloc((size_t)st.r_cap * D * 4);
     f.qkv.alloc((size_t)st.r_cap * 3 * D * 4);
     f.att.alloc((size_t)st.r_cap * D * 4);
@@ -313,11 +313,11 @@ void Model::decoder_step_f32(DecState& st, int rows, int phys_mul, int q_per_aud
     DecStateF32& f = *st.f32;
     const float scale = std::pow((float)(D / H), -0.25f);
     const StepParams* sp = st.sp_d();
-    const int64_t anc_stride = (int64_t)st.r_cap * n_ctx;
-    const size_t kv_layer = (size_t)st.r_cap * n_ctx * D;
+    const int64_t anc_stride = (int64_t)st.r_cap * st.ctx;
+    const size_t kv_layer = (size_t)st.r_cap * st.ctx * D;
     const size_t cross_layer = (size_t)st.a_cap * T * 2 * D;
     float* x = st.x.as<float>();
-    if (update_anc) launch_anc_update(st.anc.as<int>(), anc_stride, n_ctx, rows, sp, st.src_d(), stream);
+    if (update_anc) launch_anc_update(st.anc.as<int>(), anc_stride, st.ctx, rows, sp, st.src_d(), stream);
     embed_f32_kernel<<<rows, 256, 0, stream>>>(emb32, dec_pos, sp, st.tokens_d(), D, x);
     for (int l = 0; l < L_dec; ++l) {
         const BlockW& b = dec[l];
@@ -329,12 +329,12 @@ void Model::decoder_step_f32(DecState& st, int rows, int phys_mul, int q_per_aud
         }
         float* kc = f.kc.as<float>() + l * kv_layer;
         float* vc = f.vc.as<float>() + l * kv_layer;
-        append_kv_f32_kernel<<<rows, 256, 0, stream>>>(f.qkv.as<float>(), D, n_ctx, phys_mul, sp, kc, vc);
+        append_kv_f32_kernel<<<rows, 256, 0, stream>>>(f.qkv.as<float>(), D, st.ctx, phys_mul, sp, kc, vc);
         {
             AttnF32Params p{};
-            p.q = f.qkv.as<float>(); p.ldq = 3 * D; p.k = kc; p.v = vc; p.ldk = D; p.kv_row_stride = (int64_t)n_ctx * D;
+            p.q = f.qkv.as<float>(); p.ldq = 3 * D; p.k = kc; p.v = vc; p.ldk = D; p.kv_row_stride = (int64_t)st.ctx * D;
             p.n_q = rows; p.H = H; p.n_keys = -1; p.q_per_kv = 1; p.anc_base = st.anc.as<int>(); p.anc_buf_stride = anc_stride;
-            p.n_ctx = n_ctx; p.phys_mul = phys_mul; p.sp = sp; p.out = f.att.as<float>(); p.ldo = D;
+            p.n_ctx = st.ctx; p.phys_mul = phys_mul; p.sp = sp; p.out = f.att.as<float>(); p.ldo = D;
             launch_attn_f32(p, stream);
         }
         {
