@@ -123,8 +123,9 @@ struct GemmParams {
     const StepParams* sp;
 };
 
-// Epilogue of one wave's 64x64 block (acc[i][j]: n = ncolw + 16 i + 4 (lane >> 4) + r, m = mrow0 + 16 j + (lane & 15)).
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc)[4][4], const int64_t mrow0, const int ncolw, const int lane) {
+// Epilogue of one wave's 64-row x (16 NI)-column block (acc[i][j]: n = ncolw + 16 i + 4 (lane >> 4) + r, m = mrow0 + 16 j + (lane & 15)).
+template <int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc)[NI][4], const int64_t mrow0, const int ncolw, const int lane) {
     // epilogue.  Vector path (N, ldc multiples of 4: every shape of the model except an odd vocabulary): all
     // bias / positional / residual accesses are 16-byte loads requested together, branches are wave-uniform.
     const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0);
@@ -136,7 +137,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
             const int64_t m = mrow0 + j * 16 + (lane & 15);
             if (m >= p.M) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int n = ncol0 + i * 16;
                 if (n < p.N) *reinterpret_cast<floatx4*>(slab + m * p.ldc + n) = acc[i][j];
             }
@@ -147,7 +148,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
         const int Dm = p.qkv_d_model;
         const int cpos = p.sp->cache_pos;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int n = ncol0 + i * 16;
             if (n >= p.N) continue;
             const int region = n / Dm, nl = n - region * Dm;  // a 4-column group never straddles a region (D % 4 == 0)
@@ -166,9 +167,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
         return;
     }
     if (vec_ok) {
-        floatx4 bias4[4];
+        floatx4 bias4[NI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int n = ncol0 + i * 16;
             bias4[i] = (p.bias && n < p.N) ? *reinterpret_cast<const floatx4*>(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
         }
@@ -182,16 +183,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
             const bool batched = p.c_rpb <= (int64_t)p.M;
             const int64_t mb = batched ? mc / p.c_rpb : 0, mr = batched ? mc % p.c_rpb : mc;
             const int64_t crow = mb * p.c_brows + mr + p.c_roff;
-            floatx4 pos4[4], res4[4];
+            floatx4 pos4[NI], res4[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int n = ncol0 + i * 16;
                 const bool ok = mok && n < p.N;
                 pos4[i] = (p.posemb && ok) ? *reinterpret_cast<const floatx4*>(p.posemb + mr * p.N + n) : floatx4{0.f, 0.f, 0.f, 0.f};
                 res4[i] = (p.residual && ok) ? *reinterpret_cast<const floatx4*>(p.residual + crow * p.ldc + n) : floatx4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int n = ncol0 + i * 16;
                 if (!(mok && n < p.N)) continue;
                 floatx4 v = acc[i][j] + bias4[i];
@@ -217,7 +218,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
         const int64_t mb = batched ? m / p.c_rpb : 0, mr = batched ? m % p.c_rpb : m;
         const int64_t crow = mb * p.c_brows + mr + p.c_roff;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int n = ncol0 + i * 16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
