@@ -56,14 +56,19 @@ pub mod audio {
         f
     }
     /// `audio::pad_or_trim(x, len)` (audio.rs:213-228) on the last dim of a [rows, n] array
-    pub fn pad_or_trim(x: &[f32], rows: usize, len: usize) -> Vec<f32> {
-        let n = if rows == 0 { 0 } else { x.len() / rows };
+    pub fn pad_or_trim(x: &[f32], rows: usize, len: usize) -> anyhow::Result<Vec<f32>> {
+        anyhow::ensure!(rows > 0 && x.len() % rows == 0, "pad_or_trim: {} values are not {} equal rows", x.len(), rows);
+        let n = x.len() / rows;
         let mut out = vec![0f32; rows * len];
         unsafe { ffi::wrs_pad_or_trim(x.as_ptr(), rows as i64, n as i64, len as i64, out.as_mut_ptr()) };
-        out
+        Ok(out)
     }
     /// `audio::log_mel_spectrogram(audio, mel_filter)` (audio.rs:230-259): [80, n / 160]
     pub fn log_mel_spectrogram(audio: &[f32], mel_filter: Option<&[f32]>, device: i32) -> anyhow::Result<Vec<f32>> {
+        anyhow::ensure!(audio.len() >= 160, "log_mel_spectrogram: {} samples are less than one hop", audio.len());
+        if let Some(f) = mel_filter {
+            anyhow::ensure!(f.len() == 80 * 201, "log_mel_spectrogram: the mel filter must be [80, 201], got {} values", f.len());
+        }
         let mut out = vec![0f32; 80 * (audio.len() / 160)];
         let filt = mel_filter.map_or(std::ptr::null(), |f| f.as_ptr());
         check(unsafe { ffi::wrs_log_mel_spectrogram(device, audio.as_ptr(), 1, audio.len() as i64, filt, out.as_mut_ptr(), ffi::WRS_MEM_HOST) })?;
@@ -99,12 +104,19 @@ impl Whisper {
     }
     /// `AudioEncoder::forward` (model.rs:417-441): mel [n, 80, 3000] -> [n, 1500, D]
     pub fn encoder_forward(&self, mel: &[f32], n_audio: usize) -> anyhow::Result<Vec<f32>> {
+        anyhow::ensure!(n_audio > 0 && mel.len() == n_audio * 80 * 3000, "encoder_forward: mel must be [{}, 80, 3000], got {} values", n_audio, mel.len());
         let mut out = vec![0f32; n_audio * (self.dims.n_audio_ctxs * self.dims.n_audio_states) as usize];
         check(unsafe { ffi::wrs_encoder_forward(self.handle, mel.as_ptr(), n_audio as c_int, out.as_mut_ptr()) })?;
         Ok(out)
     }
     /// `TextDecoder::forward_ext(tokens, xa, offset)` (model.rs:490-522): tokens [b, s] -> logits [b, s, V]
     pub fn decoder_forward_ext(&self, tokens: &[i64], n_batch: usize, xa: Option<&[f32]>, offset: i64) -> anyhow::Result<Vec<f32>> {
+        anyhow::ensure!(n_batch > 0 && !tokens.is_empty() && tokens.len() % n_batch == 0, "decoder_forward_ext: {} tokens are not [{}, s]", tokens.len(), n_batch);
+        if let Some(x) = xa {
+            let per = (self.dims.n_audio_ctxs * self.dims.n_audio_states) as usize;
+            anyhow::ensure!(x.len() == n_batch * per, "decoder_forward_ext: xa must be [{}, n_audio_ctxs, n_audio_states], got {} values", n_batch, x.len());
+        }
+        anyhow::ensure!(offset >= 0, "decoder_forward_ext: negative offset");
         let s = tokens.len() / n_batch;
         let mut out = vec![0f32; n_batch * s * self.dims.n_vocab as usize];
         let xa = xa.map_or(std::ptr::null(), |x| x.as_ptr());
@@ -113,6 +125,7 @@ impl Whisper {
     }
     /// `Whisper::update_cache(&sources_indices)` (model.rs:591-594)
     pub fn update_cache(&self, src: &[i64]) -> anyhow::Result<()> {
+        anyhow::ensure!(!src.is_empty(), "update_cache: empty source index list");
         check(unsafe { ffi::wrs_model_update_cache(self.handle, src.as_ptr(), src.len() as c_int) })
     }
     /// `Whisper::clear_cache()` (model.rs:596-599)
@@ -276,6 +289,7 @@ impl<'a> DecodeTask<'a> {
     }
     /// `DecodeTask::run(&mel)` (decode/mod.rs:284-419): mel [80, 3000]
     pub fn run(&mut self, mel: &[f32]) -> anyhow::Result<Vec<DecodeOutput>> {
+        anyhow::ensure!(mel.len() == 80 * 3000, "DecodeTask::run: mel must be [80, 3000], got {} values", mel.len());
         let mut r = ffi::WrsDecodeResult { outputs: std::ptr::null_mut(), n_outputs: 0, n_steps: 0 };
         check(unsafe { ffi::wrs_decode_task_run(self.handle, mel.as_ptr(), 1, ffi::WRS_MEM_HOST, &mut r) })?;
         let outs = collect_outputs(&mut r);

@@ -36,6 +36,10 @@ class Cached:
         return out
 
     def update_cache(self, src):  # :53-62
+        if self.memo_long_inputs and self._memo is not None and self.cache is self._memo[1]:
+            # cross-attention K/V: the reference gathers this tensor too, and overwrites it with Linear(xa) at the next forward
+            # (:89-95) without ever reading the gathered rows; with the memo in place the gather is skipped as well
+            return
         if self.cache is not None:
             self.cache = self.cache[src]
 

@@ -1,4 +1,5 @@
 """Shared test helpers: build the same seeded synthetic model for the oracle and the HIP path."""
+import contextlib
 import dataclasses
 import functools
 
@@ -29,6 +30,26 @@ def gpu_model(W, dims_name, seed=0, **kw):
     if key not in _gpu_models:
         _gpu_models[key] = W.Whisper(MODEL_DIMS[dims_name], weights(dims_name, seed, **kw))
     return _gpu_models[key]
+
+
+@contextlib.contextmanager
+def switched_models(monkeypatch, **env):
+    """The library reads its experiment switches (WRS_DEC_PRING, WRS_DEC_FUSED, WRS_SELF_MFMA_MIN_AUDIO, WRS_DEC_BIG_GEMM_ROWS ...)
+    when a MODEL is created: inside this context every gpu_model() is built afresh under the given environment, and dropped
+    again on the way out so later tests get default-path models."""
+    saved = dict(_gpu_models)
+    _gpu_models.clear()
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    try:
+        yield
+    finally:
+        for m in _gpu_models.values():
+            m.close()
+        _gpu_models.clear()
+        _gpu_models.update(saved)
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
 
 
 def oracle_ids(n_vocab=51864):

@@ -58,18 +58,23 @@ def test_beam_search_decode_vs_oracle(gpu, dims_name, n_audio, sample_len):
 def test_beam_search_decode_with_mfma_self_attention(gpu, monkeypatch):
     """the beam-de-duplicating MFMA self-attention (csrc/attn_self_mfma.hip: what the benchmark runs; by default from 64
     audios per step) on a 3-audio beam-5 decode and a 2-audio beam-3 decode with a length penalty: free-running vs the oracle."""
-    monkeypatch.setenv("WRS_SELF_MFMA_MIN_AUDIO", "1")  # read when a decoder state is created
-    mel = mel_windows(3)
-    view, _ = _oracle_run("micro", mel, oracle_decode_options(sample_len=40, beam_size=5))
-    task = gpu.DecodeTask(gpu_model(gpu, "micro"), TokenIds.english(), gpu.DecodeOptions(sample_len=40, max_audio=3))
-    _free_run("micro_beam5_x3_mfma_self", task, mel, view, 5)
-    task.close()
-    mel = mel_windows(2)
-    view, _ = _oracle_run("nano", mel, oracle_decode_options(sample_len=24, beam_size=3, len_penalty=0.8))
-    task = gpu.DecodeTask(gpu_model(gpu, "nano"), TokenIds.english(),
-                          gpu.DecodeOptions(sample_len=24, max_audio=2, token_extract_mode=gpu.TokenExtractMode.BeamSearch(3, 1.0), len_penalty=0.8))
-    _free_run("nano_beam3_x2_mfma_self", task, mel, view, 3)
-    task.close()
+    from helpers import switched_models
+    with switched_models(monkeypatch, WRS_SELF_MFMA_MIN_AUDIO=1):  # read when the model is created
+        mel = mel_windows(3)
+        view, _ = _oracle_run("micro", mel, oracle_decode_options(sample_len=40, beam_size=5))
+        gm = gpu_model(gpu, "micro")
+        task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=40, max_audio=3))
+        _free_run("micro_beam5_x3_mfma_self", task, mel, view, 5)
+        assert DBG.last_step_path(gm) & DBG.STEP_SELF_MFMA, "the MFMA self-attention did not run"
+        task.close()
+        mel = mel_windows(2)
+        view, _ = _oracle_run("nano", mel, oracle_decode_options(sample_len=24, beam_size=3, len_penalty=0.8))
+        gm = gpu_model(gpu, "nano")
+        task = gpu.DecodeTask(gm, TokenIds.english(),
+                              gpu.DecodeOptions(sample_len=24, max_audio=2, token_extract_mode=gpu.TokenExtractMode.BeamSearch(3, 1.0), len_penalty=0.8))
+        _free_run("nano_beam3_x2_mfma_self", task, mel, view, 3)
+        assert DBG.last_step_path(gm) & DBG.STEP_SELF_MFMA
+        task.close()
 
 
 def test_greedy_equals_beam1(gpu):
@@ -242,14 +247,10 @@ def test_teacher_forced_with_early_eot(gpu):
 def test_large_batch_gemm_path_teacher_forced(gpu, monkeypatch):
     """decode steps with many rows (>= 480) run their GEMMs on the tiled kernel instead of the split-K one;
     force that path at test size and hold it to the same teacher-forced bar."""
-    import helpers
-    monkeypatch.setenv("WRS_DEC_BIG_GEMM_ROWS", "1")
-    helpers._gpu_models.pop(("micro", 0, ()), None)  # the threshold is read when a decoder state is created
-    try:
+    from helpers import switched_models
+    with switched_models(monkeypatch, WRS_DEC_BIG_GEMM_ROWS=1):  # the threshold is read when the model is created
         _teacher_forced_check(gpu, "micro", 2, 32, 0.95)
-    finally:
-        monkeypatch.delenv("WRS_DEC_BIG_GEMM_ROWS")
-        helpers._gpu_models.pop(("micro", 0, ()), None)
+        assert DBG.last_step_path(gpu_model(gpu, "micro")) & DBG.STEP_TILED, "the tiled-GEMM decode path did not run"
 
 
 def test_overlapped_mode_equals_sequential(gpu):

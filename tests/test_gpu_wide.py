@@ -45,22 +45,34 @@ def test_wide_decode_480_rows_teacher_forced(gpu, monkeypatch, pring):
     """96 audios x beam 5 = 480 decoder rows: the row count at which Model::decoder_step switches to the tiled GEMM path
     the benchmark runs (model.cpp dec_big_gemm_rows).  Decoder-only (features in), every step against the oracle.
     Both forms of that path: split-K slabs + finish kernels (default) and the persistent ring GEMM (WRS_DEC_PRING=1)."""
+    from helpers import switched_models
+    from whisper_rs_amd import debug as DBG
     n = 96
     assert n * 5 >= 480
-    if pring:
-        monkeypatch.setenv("WRS_DEC_PRING", "1")  # read when a decoder state is created
-    exact, steps = _teacher_forced_check(gpu, "wide", n, 10, WIDE_MIN_EXACT, feats=_features(n, 7), ids=TokenIds.multilingual(), cand_tol=WIDE_CAND_TOL)
-    print(f"wide, {n * 5} rows: {exact}/{steps} selections reproduced exactly")
+    # the default path runs 48 steps: the cache grows to 51 positions per row, i.e. up to 8 blocks of 32 distinct (position, row)
+    # keys per audio in the MFMA self-attention, every one written by the QKV GEMM's cache epilogue — in model context, at
+    # the benchmark's width, every step checked against the oracle (decisions forced, so rounding does not compound)
+    n_steps = 10 if pring else 48
+    with switched_models(monkeypatch, **({"WRS_DEC_PRING": 1} if pring else {})):  # switches are read when the model is created
+        exact, steps = _teacher_forced_check(gpu, "wide", n, n_steps, WIDE_MIN_EXACT, feats=_features(n, 7), ids=TokenIds.multilingual(), cand_tol=WIDE_CAND_TOL)
+        path = DBG.last_step_path(gpu_model(gpu, "wide"))
+    print(f"wide, {n * 5} rows: {exact}/{steps} selections reproduced exactly (step path bits {path:#x})")
+    assert path & DBG.STEP_TILED and bool(path & DBG.STEP_PRING) == pring
+    if not pring:
+        assert path & DBG.STEP_SELF_MFMA and path & DBG.STEP_QKV_DIRECT  # the form the benchmark runs
 
 
 @pytest.mark.parametrize("fused", [False, True], ids=["finish_kernels", "fused_prologue"])
 def test_wide_decode_small_batch_teacher_forced(gpu, monkeypatch, fused):
     """3 audios x beam 5 = 15 rows at the same width: the latency-optimised split-K path (gemm_dec / skinny logits), and
     its opt-in variant with the finish kernels folded into the next GEMM's prologue (WRS_DEC_FUSED=1, gemm_dec_fused)."""
-    if fused:
-        monkeypatch.setenv("WRS_DEC_FUSED", "1")  # read when a decoder state is created
-    exact, steps = _teacher_forced_check(gpu, "wide", 3, 24, WIDE_MIN_EXACT, feats=_features(3, 8), ids=TokenIds.multilingual(), cand_tol=WIDE_CAND_TOL)
-    print(f"wide, 15 rows: {exact}/{steps} selections reproduced exactly")
+    from helpers import switched_models
+    from whisper_rs_amd import debug as DBG
+    with switched_models(monkeypatch, **({"WRS_DEC_FUSED": 1} if fused else {})):
+        exact, steps = _teacher_forced_check(gpu, "wide", 3, 24, WIDE_MIN_EXACT, feats=_features(3, 8), ids=TokenIds.multilingual(), cand_tol=WIDE_CAND_TOL)
+        path = DBG.last_step_path(gpu_model(gpu, "wide"))
+    print(f"wide, 15 rows: {exact}/{steps} selections reproduced exactly (step path bits {path:#x})")
+    assert bool(path & DBG.STEP_FUSED) == fused and not path & DBG.STEP_TILED
 
 
 def test_wide_f32_mode_tight(gpu):

@@ -99,3 +99,52 @@ def test_safe_wrapper_calls_exist_with_the_declared_arity():
         assert m, sname
         used = set(re.findall(r"^\s*(\w+)(?::(?!:)|,)", m.group(1), re.M))
         assert used == {f for f, _ in rstructs[sname]}, (sname, used ^ {f for f, _ in rstructs[sname]})
+
+
+def _fn_bodies(txt):
+    """(name, argument list, body) of every `pub fn` of the safe wrapper (brace matching)"""
+    out = []
+    for m in re.finditer(r"pub fn (\w+)\s*(?:<[^>]*>)?\(", txt):
+        i, depth = m.end(), 1
+        while depth:  # end of the argument list
+            depth += {"(": 1, ")": -1}.get(txt[i], 0)
+            i += 1
+        args = txt[m.end():i - 1]
+        j = txt.index("{", i)
+        k, depth = j + 1, 1
+        while depth:
+            depth += {"{": 1, "}": -1}.get(txt[k], 0)
+            k += 1
+        out.append((m.group(1), args, txt[j:k]))
+    return out
+
+
+def test_safe_wrappers_guard_every_slice_they_hand_to_c():
+    """A safe Rust function must not let C read past a slice: every `&[f32]` / `&[i64]` / `&[u8]` parameter (plain or Option)
+    whose pointer goes into an `ffi::wrs_*` call has its length either passed in that same call or checked by an
+    `anyhow::ensure!` before it (the C side reads fixed shapes such as [80, 3000] from a bare pointer)."""
+    checked = 0
+    for name, args, body in _fn_bodies(open(LIB).read()):
+        if "ffi::wrs_" not in body:
+            continue
+        for a in _split_args(args):
+            if ":" not in a:
+                continue
+            pname, ptype = [x.strip() for x in a.split(":", 1)]
+            if not re.search(r"&\s*(?:'\w+\s+)?\[\s*(?:f32|i64|i32|u8|u32)\s*\]", ptype):
+                continue
+            optional = ptype.startswith("Option")
+            # the name the slice goes by where its pointer is taken: the parameter, or the closure / if-let binding of an Option
+            bound = {pname}
+            if optional:
+                bound |= set(re.findall(rf"{pname}\.map_or\([^|]*\|\s*(\w+)\s*\|", body))
+                bound |= set(re.findall(rf"if let Some\((\w+)\) = {pname}\b", body))
+            if not any(re.search(rf"\b{b}\.as_ptr\(\)", body) for b in bound):
+                continue  # the pointer never crosses the boundary
+            guarded = any(re.search(rf"ensure!\([^;]*\b{b}\.(?:len|is_empty)\(\)", body, re.S) for b in bound)
+            # ... or handed on: `x.len()` inside the call, or captured next to the pointer (`|p| (p.as_ptr(), p.len() as i32)`)
+            passed = any(re.search(rf"ffi::wrs_\w+\([^;]*\b{b}\.len\(\)", body, re.S) or
+                         re.search(rf"\b{b}\.as_ptr\(\)\s*,\s*{b}\.len\(\)", body) for b in bound)
+            assert guarded or passed, f"{name}: the length of `{pname}` is neither checked nor passed to C"
+            checked += 1
+    assert checked >= 12, checked

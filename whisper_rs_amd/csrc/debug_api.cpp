@@ -319,6 +319,12 @@ int wrs_debug_model_set_parity_f32(wrs_model* h, int enabled) {
         h->m.parity_f32 = enabled != 0;
     });
 }
+int wrs_debug_model_last_step_path(const wrs_model* h, int32_t* path) {
+    return guarded([&] {
+        WRS_REQUIRE(h && path, "null argument");
+        *path = h->m.last_step_path;
+    });
+}
 int wrs_debug_set_encoder_stop(wrs_model* h, int n_launches) { if (h) h->m.debug_enc_stop = n_launches; return 0; }
 // copy an internal encoder workspace buffer to host as f32. which: 0 x(f32) 1 xn 2 qkv 3 att 4 h 5 c1 6 mel_t 7 xa16
 int wrs_debug_read_encoder(wrs_model* h, int which, float* out, int64_t n) {

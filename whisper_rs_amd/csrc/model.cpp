@@ -56,6 +56,8 @@ void StageTimer::reset() {
 // ------------------------------------------------------------------------------------------ model
 Model::~Model() {
     for (auto e : cross_ev) (void)hipEventDestroy(e);
+    for (auto e : enc_ws.stage_read) if (e) (void)hipEventDestroy(e);
+    if (enc_ws.stage_copied) (void)hipEventDestroy(enc_ws.stage_copied);
     if (stream) (void)hipStreamDestroy(stream);
     delete timer;
 }
@@ -321,15 +323,31 @@ void Model::load_mel(const float* mel, int n, int mem_kind, int64_t n_frames, in
     ensure_encoder_ws(n);
     const size_t bytes = (size_t)n * 80 * n_frames * 4;
     const float* src = mel;
-    DevBuf tmp;
+    int sb = -1;
     if (mem_kind == WRS_MEM_HOST) {
-        tmp.alloc(bytes);
-        HIP_CHECK(hipMemcpyAsync(tmp.p, mel, bytes, hipMemcpyHostToDevice, stream));
-        src = tmp.as<float>();
+        // Host spectrogram: through one of two persistent staging buffers (nothing is allocated or freed per call: hipFree is
+        // a device-wide synchronisation and this runs once per window batch of a pool worker).  The copy runs on the utility
+        // stream and only IT is waited for — the caller's buffer is free when this returns, and a work stream that still holds
+        // the previous batch's encoder (overlapped mode) is not drained.
+        EncoderWorkspace& w = enc_ws;
+        sb = w.stage_next;
+        w.stage_next ^= 1;
+        hipStream_t us = utility_stream();
+        if (w.stage_read[sb]) HIP_CHECK(hipStreamWaitEvent(us, w.stage_read[sb], 0));  // the kernel that last read this buffer
+        w.mel_stage[sb].ensure(bytes);
+        HIP_CHECK(hipMemcpyAsync(w.mel_stage[sb].p, mel, bytes, hipMemcpyHostToDevice, us));
+        if (!w.stage_copied) HIP_CHECK(hipEventCreateWithFlags(&w.stage_copied, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(w.stage_copied, us));
+        HIP_CHECK(hipEventSynchronize(w.stage_copied));
+        HIP_CHECK(hipStreamWaitEvent(stream, w.stage_copied, 0));
+        src = w.mel_stage[sb].as<float>();
     }
     launch_mel_prep(src, n, n_frames, 80 * n_frames, seek, enc_ws.mel_t.as<half_t>(), stream);
     if (parity_f32) load_mel_f32(src, n, n_frames, 80 * n_frames, seek);
-    if (mem_kind == WRS_MEM_HOST) HIP_CHECK(hipStreamSynchronize(stream));  // tmp is freed on return
+    if (sb >= 0) {
+        if (!enc_ws.stage_read[sb]) HIP_CHECK(hipEventCreateWithFlags(&enc_ws.stage_read[sb], hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(enc_ws.stage_read[sb], stream));
+    }
 }
 
 void Model::load_mel_window(const float* mel_dev, int64_t n_frames, int64_t seek, int slot) {
@@ -577,10 +595,12 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     };
 
     if (big && !dec_slab_path) {
+        last_step_path = 1 | 2;
         decoder_step_big(st, rows, phys_mul, q_per_audio, update_anc, want_logits);
         return;
     }
     if (rows <= 16 && dec_fused_tiny) {
+        last_step_path = 4;
         decoder_step_tiny(st, rows, phys_mul, q_per_audio, update_anc, want_logits);
         return;
     }
@@ -598,6 +618,7 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     // fp16, new key / value rows appended to the cache: no fp32 slab to write and re-read; WRS_DEC_QKV_SLAB=1 keeps the slab)
     static const bool qkv_slab_forced = getenv("WRS_DEC_QKV_SLAB") && getenv("WRS_DEC_QKV_SLAB")[0] == '1';
     const bool qkv_direct = self_mfma && big && !qkv_slab_forced;
+    last_step_path = (big ? 1 : 0) | (self_mfma ? 8 : 0) | (qkv_direct ? 16 : 0);
     if (self_mfma) {
         Timed tm(timer, "dec_self_keys", stream);
         launch_self_keys(st.anc.as<int>(), anc_stride, st.ctx, n_audio, q_per_audio, sp, self_klist, st.self_keys_stride, self_kcount, qkv_direct, stream);

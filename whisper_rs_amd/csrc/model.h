@@ -46,6 +46,12 @@ struct EncoderWorkspace {
     int n_encoded = 0;  // windows whose encoder output currently sits in xa16/xa32
     uint64_t epoch = 0;  // bumped by every write of xa16/xa32 (a DecodeTask remembers the epoch its outputs' features belong to)
     DevBuf mel_t, c1, x, xn, qkv, kp, vp, att, h, xa16, xa32;
+    // host spectrograms (Model::load_mel): two persistent device staging buffers used in turn, the event after the kernel that
+    // last read each, and the event of the last upload
+    DevBuf mel_stage[2];
+    hipEvent_t stage_read[2] = {nullptr, nullptr};
+    hipEvent_t stage_copied = nullptr;
+    int stage_next = 0;
 };
 
 // workspace of the batched prompt prefill (Model::decoder_prefill): rows are (audio, prompt position)
@@ -150,6 +156,7 @@ struct Model {
     bool dec_fused_tiny = false;            // <= 16 rows, WRS_DEC_FUSED=1: finish kernels fused into the next GEMM's prologue (8 launches per layer instead of 12, but slower: DESIGN.md section 4)
     int self_mfma_min_audio = 64;           // beam-de-duplicating MFMA self-attention from this many audios per step (WRS_SELF_MFMA_MIN_AUDIO; 0 = never)
     bool dec_slab_path = true;              // split-K fp32 slabs + finish kernels; WRS_DEC_PRING=1 selects the persistent-ring form (slower, see model.cpp)
+    int last_step_path = 0;                 // diagnosis: bits of the path the last decoder_step took (1 tiled GEMMs, 2 persistent ring, 4 fused prologue, 8 MFMA self-attention, 16 QKV hand-over)
     void read_switches();                   // experiment switches from the environment, ONCE per model (wrs_model_create)
     // live timing of the dominant decode kernel (cross-attention) with HIP events on this stream: every
     // `cross_ev_every`-th decode step is launched eagerly (not from the graph) with event pairs around the
