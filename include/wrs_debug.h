@@ -136,10 +136,11 @@ int wrs_debug_transcribe_bookkeeping(int32_t ts_begin, int64_t n_audio_ctxs, int
  * free-running decode must reproduce the fp32 oracle's ids and beam sources to the last step.  Slow, small models only;
  * choose before wrs_model_finalize (also: environment WRS_PARITY_F32=1 at wrs_model_create). */
 int wrs_debug_model_set_parity_f32(wrs_model* m, int enabled);
-/* which form of Model::decoder_step the last step took: bit 0 tiled GEMMs (>= dec_big_gemm_rows rows), 1 persistent ring GEMMs
+/* which forms of Model::decoder_step this model has taken since it was created (OR; steps replayed from a captured graph
+ * count through their capture): bit 0 tiled GEMMs (>= dec_big_gemm_rows rows), 1 persistent ring GEMMs
  * (WRS_DEC_PRING), 2 fused prologue (WRS_DEC_FUSED, <= 16 rows), 3 MFMA self-attention, 4 QKV handed over without slabs.
  * The experiment switches are read from the environment when the MODEL is created. */
-int wrs_debug_model_last_step_path(const wrs_model* m, int32_t* path);
+int wrs_debug_model_step_paths(const wrs_model* m, int32_t* path);
 int wrs_debug_set_encoder_stop(wrs_model* m, int n_launches);
 int wrs_debug_read_encoder(wrs_model* m, int which, float* out, int64_t n);
 

@@ -65,7 +65,7 @@ def test_beam_search_decode_with_mfma_self_attention(gpu, monkeypatch):
         gm = gpu_model(gpu, "micro")
         task = gpu.DecodeTask(gm, TokenIds.english(), gpu.DecodeOptions(sample_len=40, max_audio=3))
         _free_run("micro_beam5_x3_mfma_self", task, mel, view, 5)
-        assert DBG.last_step_path(gm) & DBG.STEP_SELF_MFMA, "the MFMA self-attention did not run"
+        assert DBG.step_paths(gm) & DBG.STEP_SELF_MFMA, "the MFMA self-attention did not run"
         task.close()
         mel = mel_windows(2)
         view, _ = _oracle_run("nano", mel, oracle_decode_options(sample_len=24, beam_size=3, len_penalty=0.8))
@@ -73,7 +73,7 @@ def test_beam_search_decode_with_mfma_self_attention(gpu, monkeypatch):
         task = gpu.DecodeTask(gm, TokenIds.english(),
                               gpu.DecodeOptions(sample_len=24, max_audio=2, token_extract_mode=gpu.TokenExtractMode.BeamSearch(3, 1.0), len_penalty=0.8))
         _free_run("nano_beam3_x2_mfma_self", task, mel, view, 3)
-        assert DBG.last_step_path(gm) & DBG.STEP_SELF_MFMA
+        assert DBG.step_paths(gm) & DBG.STEP_SELF_MFMA
         task.close()
 
 
@@ -204,7 +204,7 @@ def test_capacity_and_errors(gpu):
 # Teacher-forced verification: the device follows the ORACLE's beam decisions at every step, so every step of a long
 # decode is checked in ONE device run (the free-running comparison above re-runs the device after each near-tie).
 def _teacher_forced_check(gpu, dims_name, n_audio, sample_len, min_exact_frac, feats=None, ids=None, okw=None, gkw=None, cand_tol=P.CAND_ERR,
-                          f32_mode=False, **wkw):
+                          f32_mode=False, quantile_bounds=None, **wkw):
     """feats: encoder outputs [n_audio, 1500, D] (decoder-only run through wrs_debug_decode_forced_features) instead of
     the synthetic mel windows.  okw / gkw: extra oracle / device decode options."""
     ids = ids or TokenIds.for_vocab(MODEL_DIMS[dims_name].n_vocab)
@@ -231,7 +231,8 @@ def _teacher_forced_check(gpu, dims_name, n_audio, sample_len, min_exact_frac, f
     task.close()
     if f32_mode:
         gm.close()
-    exact, steps, _ = P.teacher_forced_check(f"{dims_name}_tf_x{n_audio}{'_f32' if f32_mode else ''}", glp, gid, gns, view, 5, ids.eot, min_exact_frac, cand_tol)
+    exact, steps, _ = P.teacher_forced_check(f"{dims_name}_tf_x{n_audio}{'_f32' if f32_mode else ''}", glp, gid, gns, view, 5, ids.eot, min_exact_frac, cand_tol,
+                                             quantile_bounds=quantile_bounds)
     return exact, steps
 
 
@@ -250,7 +251,7 @@ def test_large_batch_gemm_path_teacher_forced(gpu, monkeypatch):
     from helpers import switched_models
     with switched_models(monkeypatch, WRS_DEC_BIG_GEMM_ROWS=1):  # the threshold is read when the model is created
         _teacher_forced_check(gpu, "micro", 2, 32, 0.95)
-        assert DBG.last_step_path(gpu_model(gpu, "micro")) & DBG.STEP_TILED, "the tiled-GEMM decode path did not run"
+        assert DBG.step_paths(gpu_model(gpu, "micro")) & DBG.STEP_TILED, "the tiled-GEMM decode path did not run"
 
 
 def test_overlapped_mode_equals_sequential(gpu):

@@ -18,6 +18,12 @@ torch.set_num_threads(16)
 # candidate log-probs are within 1.7e-2 of the fp32 oracle's (measured), against 6e-3 at D <= 768; the SAME model in f32
 # parity mode agrees to 1e-4 (test_wide_f32_mode_tight), so the difference is fp16 rounding.
 WIDE_CAND_TOL = 3e-2
+# The 48-step run below compares 138 000 candidates: the MAXIMUM of that many samples of rounding noise exceeds 3e-2 in a few
+# steps (measured per step over 48 steps, scripts/diag_wide_error.py: median 1.6e-3 at step 0, 3.3e-3 from step 10 on and flat
+# thereafter — no growth with the cache length —, 99.9th percentile 2.0-2.9e-2, maximum 2.1-3.6e-2).  What that run bounds is
+# the DISTRIBUTION — median, 99th and 99.9th percentile, each tighter than the 10-step bound on the maximum — plus a hard cap.
+WIDE_LONG_QUANTILES = (5e-3, 2e-2, 3e-2)
+WIDE_LONG_CAP = 4.5e-2
 # ... and with errors of that size 8-11 % of the (step, audio) beam selections of this random-weight model are near-ties;
 # every one of them is priced in the oracle's own scores (margin <= 2 x the measured error) by tests/parity.py
 WIDE_MIN_EXACT = 0.85
@@ -54,8 +60,9 @@ def test_wide_decode_480_rows_teacher_forced(gpu, monkeypatch, pring):
     # the benchmark's width, every step checked against the oracle (decisions forced, so rounding does not compound)
     n_steps = 10 if pring else 48
     with switched_models(monkeypatch, **({"WRS_DEC_PRING": 1} if pring else {})):  # switches are read when the model is created
-        exact, steps = _teacher_forced_check(gpu, "wide", n, n_steps, WIDE_MIN_EXACT, feats=_features(n, 7), ids=TokenIds.multilingual(), cand_tol=WIDE_CAND_TOL)
-        path = DBG.last_step_path(gpu_model(gpu, "wide"))
+        exact, steps = _teacher_forced_check(gpu, "wide", n, n_steps, WIDE_MIN_EXACT, feats=_features(n, 7), ids=TokenIds.multilingual(),
+                                             cand_tol=WIDE_CAND_TOL if pring else WIDE_LONG_CAP, quantile_bounds=None if pring else WIDE_LONG_QUANTILES)
+        path = DBG.step_paths(gpu_model(gpu, "wide"))
     print(f"wide, {n * 5} rows: {exact}/{steps} selections reproduced exactly (step path bits {path:#x})")
     assert path & DBG.STEP_TILED and bool(path & DBG.STEP_PRING) == pring
     if not pring:
@@ -70,7 +77,7 @@ def test_wide_decode_small_batch_teacher_forced(gpu, monkeypatch, fused):
     from whisper_rs_amd import debug as DBG
     with switched_models(monkeypatch, **({"WRS_DEC_FUSED": 1} if fused else {})):
         exact, steps = _teacher_forced_check(gpu, "wide", 3, 24, WIDE_MIN_EXACT, feats=_features(3, 8), ids=TokenIds.multilingual(), cand_tol=WIDE_CAND_TOL)
-        path = DBG.last_step_path(gpu_model(gpu, "wide"))
+        path = DBG.step_paths(gpu_model(gpu, "wide"))
     print(f"wide, 15 rows: {exact}/{steps} selections reproduced exactly (step path bits {path:#x})")
     assert bool(path & DBG.STEP_FUSED) == fused and not path & DBG.STEP_TILED
 

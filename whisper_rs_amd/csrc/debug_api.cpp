@@ -319,10 +319,10 @@ int wrs_debug_model_set_parity_f32(wrs_model* h, int enabled) {
         h->m.parity_f32 = enabled != 0;
     });
 }
-int wrs_debug_model_last_step_path(const wrs_model* h, int32_t* path) {
+int wrs_debug_model_step_paths(const wrs_model* h, int32_t* path) {
     return guarded([&] {
         WRS_REQUIRE(h && path, "null argument");
-        *path = h->m.last_step_path;
+        *path = h->m.step_paths_seen;
     });
 }
 int wrs_debug_set_encoder_stop(wrs_model* h, int n_launches) { if (h) h->m.debug_enc_stop = n_launches; return 0; }

@@ -595,12 +595,12 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     };
 
     if (big && !dec_slab_path) {
-        last_step_path = 1 | 2;
+        step_paths_seen |= 1 | 2;
         decoder_step_big(st, rows, phys_mul, q_per_audio, update_anc, want_logits);
         return;
     }
     if (rows <= 16 && dec_fused_tiny) {
-        last_step_path = 4;
+        step_paths_seen |= 4;
         decoder_step_tiny(st, rows, phys_mul, q_per_audio, update_anc, want_logits);
         return;
     }
@@ -618,7 +618,7 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     // fp16, new key / value rows appended to the cache: no fp32 slab to write and re-read; WRS_DEC_QKV_SLAB=1 keeps the slab)
     static const bool qkv_slab_forced = getenv("WRS_DEC_QKV_SLAB") && getenv("WRS_DEC_QKV_SLAB")[0] == '1';
     const bool qkv_direct = self_mfma && big && !qkv_slab_forced;
-    last_step_path = (big ? 1 : 0) | (self_mfma ? 8 : 0) | (qkv_direct ? 16 : 0);
+    step_paths_seen |= (big ? 1 : 0) | (self_mfma ? 8 : 0) | (qkv_direct ? 16 : 0);
     if (self_mfma) {
         Timed tm(timer, "dec_self_keys", stream);
         launch_self_keys(st.anc.as<int>(), anc_stride, st.ctx, n_audio, q_per_audio, sp, self_klist, st.self_keys_stride, self_kcount, qkv_direct, stream);

@@ -156,7 +156,7 @@ struct Model {
     bool dec_fused_tiny = false;            // <= 16 rows, WRS_DEC_FUSED=1: finish kernels fused into the next GEMM's prologue (8 launches per layer instead of 12, but slower: DESIGN.md section 4)
     int self_mfma_min_audio = 64;           // beam-de-duplicating MFMA self-attention from this many audios per step (WRS_SELF_MFMA_MIN_AUDIO; 0 = never)
     bool dec_slab_path = true;              // split-K fp32 slabs + finish kernels; WRS_DEC_PRING=1 selects the persistent-ring form (slower, see model.cpp)
-    int last_step_path = 0;                 // diagnosis: bits of the path the last decoder_step took (1 tiled GEMMs, 2 persistent ring, 4 fused prologue, 8 MFMA self-attention, 16 QKV hand-over)
+    int step_paths_seen = 0;                // diagnosis: OR of the forms decoder_step has taken on this model (1 tiled GEMMs, 2 persistent ring, 4 fused prologue, 8 MFMA self-attention, 16 QKV hand-over)
     void read_switches();                   // experiment switches from the environment, ONCE per model (wrs_model_create)
     // live timing of the dominant decode kernel (cross-attention) with HIP events on this stream: every
     // `cross_ev_every`-th decode step is launched eagerly (not from the graph) with event pairs around the

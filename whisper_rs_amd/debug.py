@@ -56,7 +56,7 @@ SYMBOLS = {
     "wrs_debug_transcribe_bookkeeping": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                                    C.c_void_p, P(L.TranscribeOutputC)]),
     "wrs_debug_model_set_parity_f32": (C.c_int, [C.c_void_p, C.c_int]),
-    "wrs_debug_model_last_step_path": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "wrs_debug_model_step_paths": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "wrs_debug_set_encoder_stop": (C.c_int, [C.c_void_p, C.c_int]),
     "wrs_debug_read_encoder": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
 }
@@ -167,8 +167,8 @@ def parity_f32_model(dims, weights, device=0):
 STEP_TILED, STEP_PRING, STEP_FUSED, STEP_SELF_MFMA, STEP_QKV_DIRECT = 1, 2, 4, 8, 16
 
 
-def last_step_path(model):
-    """bits of the form of Model::decoder_step the model's last decode step took (include/wrs_debug.h)"""
+def step_paths(model):
+    """OR of the forms of Model::decoder_step this model has taken since it was created (include/wrs_debug.h)"""
     v = C.c_int32(0)
-    L.check(lib().wrs_debug_model_last_step_path(model._h, C.byref(v)))
+    L.check(lib().wrs_debug_model_step_paths(model._h, C.byref(v)))
     return v.value
