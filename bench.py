@@ -27,7 +27,7 @@ import torch
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_ACHIEVABLE_GBS = 6300.0  # what a device copy sustains
 MFMA_PEAK_F16 = 2.5e15  # dense fp16 MFMA peak, same guide
-PMC_FILE = "profiles/r02_pmc_fetch_write_b256.json"
+PMC_FILE = "profiles/r03_pmc_fetch_write_b307.json"
 
 
 def end_to_end_roofline(dims, n_audio, beam, n_steps, sample_begin=1):
