@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
         }
         for (int ks : {1, 2, 4}) shapes.push_back({"d_DxD", D, D, true, false, false, ks});
         shapes.push_back({"d_qkv", 3 * D, D, true, false, false, 1});
+        shapes.push_back({"d_qkvd", 3 * D, D, false, false, false, -1});  // the step's own form: fp16 query + key / value rows into the cache
         shapes.push_back({"d_mlp1", 4 * D, D, false, false, true, 1});
         for (int ks : {1, 2, 4, 8}) shapes.push_back({"d_mlp2", D, 4 * D, true, false, false, ks});
         shapes.push_back({"d_logit", 51968, D, true, false, false, 1});
@@ -40,10 +41,19 @@ int main(int argc, char** argv) {
         const int64_t mp = round_up(M, 128);
         a.alloc((size_t)mp * sh.K * 2 + 4096); fill(a);
         w.alloc((size_t)round_up(sh.N, 128) * sh.K * 2); fill(w);
-        c.alloc((size_t)mp * sh.N * 4 * sh.ksplit); bias.alloc(sh.N * 4);
+        c.alloc((size_t)mp * sh.N * 4 * std::max(sh.ksplit, 1)); bias.alloc(sh.N * 4);
         GemmA A{a.as<half_t>(), sh.K};
         if (dec) { A.packed = 1; A.packed_rows = mp; }
         GemmEpi e; e.c = c.p; e.c_f32 = sh.f32out; e.ldc = sh.N;
+        DevBuf kc, vc, spb;
+        if (sh.ksplit < 0) {  // QKV-to-cache epilogue: 32 cached positions per row, this step writes position 7
+            const int ctx = 32;
+            kc.alloc((size_t)mp * ctx * D * 2); vc.alloc((size_t)mp * ctx * D * 2); spb.alloc(sizeof(StepParams));
+            StepParams sp{}; sp.cache_pos = 7; sp.n_rows = (int)M;
+            HIP_CHECK(hipMemcpy(spb.p, &sp, sizeof(sp), hipMemcpyHostToDevice));
+            e.bias = bias.as<float>(); e.scale = 0.35f; e.scale_n_end = 2 * D; e.ldc = D; e.qkv_d_model = D;
+            e.kcache = kc.as<half_t>(); e.vcache = vc.as<half_t>(); e.cache_row_stride = (int64_t)ctx * D; e.sp = spb.as<StepParams>();
+        } else
         if (sh.ksplit > 1) { e.ksplit = sh.ksplit; e.slab_stride = mp * sh.N; }
         else { e.bias = bias.as<float>(); e.act = sh.gelu; if (dec && !sh.f32out) e.c_packed = 1; }
         if (sh.res) e.residual = c.as<float>();

@@ -150,6 +150,8 @@ __device__ __forceinline__ void slab_sum8(const float* __restrict__ slab, int ks
     }
 }
 
+// NT: the cached K / V rows are requested with the non-temporal hint (every row is used once per launch by one wave)
+template <bool NT>
 __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[4][SM_WAVE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -192,8 +194,13 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
         for (int i = 0; i < 4; ++i) {
             const int ek = __shfl(e, i * 8 + lkey);
             const unsigned boff = audio_b + (unsigned)((ek >> 9) & 7) * row_stride_b + (unsigned)(ek & 511) * (unsigned)(D * 2) + (unsigned)(lchunk * 16);
-            kf[i] = *reinterpret_cast<const half8*>(kcb + boff);
-            vf[i] = *reinterpret_cast<const half8*>(vcb + boff);
+            if (NT) {
+                kf[i] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(kcb + boff));
+                vf[i] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(vcb + boff));
+            } else {
+                kf[i] = *reinterpret_cast<const half8*>(kcb + boff);
+                vf[i] = *reinterpret_cast<const half8*>(vcb + boff);
+            }
         }
     };
     e_nxt = entry_raw(1);
@@ -352,13 +359,23 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
     }
 }
 
+// Non-temporal K / V loads (they bypass the CU's L1: every row is used once, by one wave): 65.2 -> 50.6 us on the kernel
+// test's shapes (profiles/r03_self_attention_nontemporal.log).  The PMC comparison of round 2 had shown the texture-address
+// unit stalled by the L1 70x more often than in a loads-only kernel of the same address pattern; this is that stall.
+// WRS_SELF_NT=0 (read once per process) selects the plain loads for comparison.
+static bool self_mfma_nt() {
+    static const bool nt = !(getenv("WRS_SELF_NT") && getenv("WRS_SELF_NT")[0] == '0');
+    return nt;
+}
+
 void launch_attn_self_mfma_q16(const half_t* q16, half_t* kc, half_t* vc, int n_ctx, int n_rows, int G, int H, int D, const StepParams* sp,
                                const int* klist, int klist_stride, const int* kcount, half_t* out, hipStream_t s) {
     WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && q16, "attn_self_mfma: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
     WRS_REQUIRE(G >= 1 && G <= 8 && n_rows % G == 0 && klist && kcount, "attn_self_mfma: bad group size %d for %d rows", G, n_rows);
     WRS_REQUIRE((int64_t)n_rows * n_ctx * D * 2 < (1ll << 32), "attn_self_mfma: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
     SelfMfmaParams p{nullptr, 1, 0, nullptr, 1.f, kc, vc, n_ctx, G, H, D, sp, klist, klist_stride, kcount, out, q16};
-    attn_self_mfma_kernel<<<(n_rows / G) * ((H + 3) / 4), 256, 0, s>>>(p);
+    if (self_mfma_nt()) attn_self_mfma_kernel<true><<<(n_rows / G) * ((H + 3) / 4), 256, 0, s>>>(p);
+    else attn_self_mfma_kernel<false><<<(n_rows / G) * ((H + 3) / 4), 256, 0, s>>>(p);
 }
 
 void launch_attn_self_mfma(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc, int n_ctx,
@@ -369,7 +386,8 @@ void launch_attn_self_mfma(const float* qkv_slab, int ksplit, int m_pad, const f
     WRS_REQUIRE((int64_t)n_rows * n_ctx * D * 2 < (1ll << 32), "attn_self_mfma: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
     SelfMfmaParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, n_ctx, G, H, D, sp, klist, klist_stride, kcount, out, nullptr};
     const int n_audio = n_rows / G;
-    attn_self_mfma_kernel<<<n_audio * ((H + 3) / 4), 256, 0, s>>>(p);
+    if (self_mfma_nt()) attn_self_mfma_kernel<true><<<n_audio * ((H + 3) / 4), 256, 0, s>>>(p);
+    else attn_self_mfma_kernel<false><<<n_audio * ((H + 3) / 4), 256, 0, s>>>(p);
 }
 
 }  // namespace wrs

@@ -163,11 +163,19 @@ template <int NV, int NT>
 __global__ __launch_bounds__(NT) void finish_residual_ln_kernel(float* __restrict__ x, const float* __restrict__ slab,
                                                                 int ksplit, int m_pad, const float* __restrict__ bias,
                                                                 const float* __restrict__ g, const float* __restrict__ b,
-                                                                int M, int D, half_t* __restrict__ xn) {
+                                                                int M, int D, half_t* __restrict__ xn, int xcd_rows) {
     constexpr int NW = NT / 64;
     __shared__ float red[2 * NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row = blockIdx.x;
+    // XCD-aware row order (workgroups are dealt round-robin over the 8 XCDs): XCD x takes the contiguous rows
+    // [x * per, (x + 1) * per), per a multiple of 8.  A 128-byte line of the packed activation output holds the 16-byte
+    // chunks of 8 consecutive rows: with row = blockIdx.x eight different L2s each wrote back an eighth of every line.
+    // Speed only.  xcd_rows = 0: plain order.
+    int row = blockIdx.x;
+    if (xcd_rows > 0) {
+        row = (int)(blockIdx.x & 7) * xcd_rows + (int)(blockIdx.x >> 3);
+        if (row >= M) return;  // whole workgroup, before any barrier
+    }
     floatx4 v[NV];
     float s = 0.f;
 #pragma unroll
@@ -186,6 +194,14 @@ __global__ __launch_bounds__(NT) void finish_residual_ln_kernel(float* __restric
         }
     }
     if (!xn) return;
+    // LayerNorm weights requested now: behind the two barriers below they would be one more dependent memory round trip
+    floatx4 gg[NV], bb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * NT + tid) * 4;
+        gg[i] = c < D ? *reinterpret_cast<const floatx4*>(g + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+        bb[i] = c < D ? *reinterpret_cast<const floatx4*>(b + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+    }
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
@@ -216,11 +232,9 @@ __global__ __launch_bounds__(NT) void finish_residual_ln_kernel(float* __restric
     for (int i = 0; i < NV; ++i) {
         const int c = (i * NT + tid) * 4;
         if (c < D) {
-            const floatx4 gg = *reinterpret_cast<const floatx4*>(g + c);
-            const floatx4 bb = *reinterpret_cast<const floatx4*>(b + c);
             half4 y;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = (_Float16)((v[i][r] - mean) * rstd * gg[r] + bb[r]);
+            for (int r = 0; r < 4; ++r) y[r] = (_Float16)((v[i][r] - mean) * rstd * gg[i][r] + bb[i][r]);
             *reinterpret_cast<half4*>(xn + pa_off(row, c, D >> 5)) = y;  // packed activation order
         }
     }
@@ -229,10 +243,13 @@ __global__ __launch_bounds__(NT) void finish_residual_ln_kernel(float* __restric
 void launch_finish_residual_ln(float* x, const float* slab, int ksplit, int m_pad, const float* bias, const float* g,
                                const float* b, int M, int D, half_t* xn, hipStream_t s) {
     WRS_REQUIRE(D % 32 == 0 && D <= 2048, "finish_residual_ln: D=%d unsupported", D);
-    if (D == 1280) finish_residual_ln_kernel<1, 320><<<M, 320, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
-    else if (D == 768) finish_residual_ln_kernel<1, 192><<<M, 192, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
-    else if (D <= 1024) finish_residual_ln_kernel<1, 256><<<M, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
-    else finish_residual_ln_kernel<2, 256><<<M, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn);
+    static const bool plain = getenv("WRS_FINISH_PLAIN_ROWS") && getenv("WRS_FINISH_PLAIN_ROWS")[0] == '1';  // experiment switch
+    const int per = (M >= 64 && !plain) ? (int)round_up(cdiv(M, 8), 8) : 0;  // rows per XCD (few rows: plain order)
+    const unsigned grid = per ? 8u * (unsigned)per : (unsigned)M;
+    if (D == 1280) finish_residual_ln_kernel<1, 320><<<grid, 320, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn, per);
+    else if (D == 768) finish_residual_ln_kernel<1, 192><<<grid, 192, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn, per);
+    else if (D <= 1024) finish_residual_ln_kernel<1, 256><<<grid, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn, per);
+    else finish_residual_ln_kernel<2, 256><<<grid, 256, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn, per);
 }
 
 // MLP-1 finish: split-K reduction + bias + exact GELU (reference model.rs:279-286) -> packed fp16 activations

@@ -123,8 +123,25 @@ struct GemmParams {
     const StepParams* sp;
 };
 
+// Two 4-column groups of a lane's row (fp32, columns 16 i + 4 q .. and 16 (i + 1) + 4 q .. with q = lane >> 4) -> fp16, then
+// v_permlane16_swap exchanges the odd lane rows of group i with the even lane rows of group i + 1: afterwards a lane holds 8
+// CONSECUTIVE columns — of group i + (q & 1), starting at column 8 (q >> 1) of it — as one 16-byte vector (columns ascending).
+// Every lane of the wave must call it (the exchange reads the other rows' registers whatever their EXEC state).
+__device__ __forceinline__ uint4 epi_pair16(const floatx4 a, const floatx4 b) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    unsigned ax = __builtin_bit_cast(unsigned, half2v{(_Float16)a[0], (_Float16)a[1]});
+    unsigned ay = __builtin_bit_cast(unsigned, half2v{(_Float16)a[2], (_Float16)a[3]});
+    unsigned bx = __builtin_bit_cast(unsigned, half2v{(_Float16)b[0], (_Float16)b[1]});
+    unsigned by = __builtin_bit_cast(unsigned, half2v{(_Float16)b[2], (_Float16)b[3]});
+    const auto x = __builtin_amdgcn_permlane16_swap(ax, bx, false, false);  // {rows a0 b0 a2 b2, rows a1 b1 a3 b3}
+    const auto y = __builtin_amdgcn_permlane16_swap(ay, by, false, false);
+    return uint4{x[0], y[0], x[1], y[1]};
+}
+
 // Epilogue of one wave's 64-row x (16 NI)-column block (acc[i][j]: n = ncolw + 16 i + 4 (lane >> 4) + r, m = mrow0 + 16 j + (lane & 15)).
-template <int NI>
+// PF: request the residual of the next row group before the current one is stored (kernels with registers to spare: the
+// row-major kernels of the encoder; the 12-wave ring kernel has 168 registers per lane and would spill).
+template <int NI, bool PF = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc)[NI][4], const int64_t mrow0, const int ncolw, const int lane) {
     // epilogue.  Vector path (N, ldc multiples of 4: every shape of the model except an odd vocabulary): all
     // bias / positional / residual accesses are 16-byte loads requested together, branches are wave-uniform.
@@ -144,24 +161,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
         }
         return;
     }
+    const int q16 = lane >> 4;
     if (p.qkv_d_model > 0) {  // q -> fp16 [M, ldc]; k / v -> the cache row of m at the step's position (launcher checks the shape)
         const int Dm = p.qkv_d_model;
         const int cpos = p.sp->cache_pos;
+        static_assert(NI % 2 == 0, "column groups are stored in pairs");
+        // after the row exchange (epi_pair16) this lane owns 8 consecutive columns of group i + (q & 1): one 16-byte store
+        // instead of two 8-byte ones; a 16-column group never straddles q / k / v (D % 16 == 0, checked by the launcher)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int n = ncol0 + i * 16;
-            if (n >= p.N) continue;
-            const int region = n / Dm, nl = n - region * Dm;  // a 4-column group never straddles a region (D % 4 == 0)
-            const floatx4 b4 = p.bias ? *reinterpret_cast<const floatx4*>(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
-            const float sc = n < p.scale_n_end ? p.scale : 1.f;
+        for (int i = 0; i < NI; i += 2) {
+            const int na = ncol0 + i * 16, nb = na + 16;
+            const floatx4 ba = (p.bias && na < p.N) ? *reinterpret_cast<const floatx4*>(p.bias + na) : floatx4{0.f, 0.f, 0.f, 0.f};
+            const floatx4 bb = (p.bias && nb < p.N) ? *reinterpret_cast<const floatx4*>(p.bias + nb) : floatx4{0.f, 0.f, 0.f, 0.f};
+            const float sa = na < p.scale_n_end ? p.scale : 1.f, sb = nb < p.scale_n_end ? p.scale : 1.f;
+            const int n = ncolw + 16 * (i + (q16 & 1)) + 8 * (q16 >> 1);  // first of this lane's 8 columns after the exchange
+            const int region = n / Dm, nl = n - region * Dm;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int64_t m = mrow0 + j * 16 + (lane & 15);
-                if (m >= p.M) continue;
-                const floatx4 v = (acc[i][j] + b4) * sc;
+                const uint4 w = epi_pair16((acc[i][j] + ba) * sa, (acc[i + 1][j] + bb) * sb);
+                if (m >= p.M || n >= p.N) continue;
                 half_t* dst = region == 0 ? reinterpret_cast<half_t*>(p.c) + m * p.ldc + nl
                                           : (region == 1 ? p.kcache : p.vcache) + m * p.cache_row_stride + (int64_t)cpos * Dm + nl;
-                *reinterpret_cast<half4*>(dst) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<uint4*>(dst) = w;
             }
         }
         return;
@@ -173,36 +195,70 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
             const int n = ncol0 + i * 16;
             bias4[i] = (p.bias && n < p.N) ? *reinterpret_cast<const floatx4*>(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
         }
+        // rows are batched only for the conv outputs; elsewhere c_rpb is "infinite" and the 64-bit division and modulo
+        // (software routines of a few hundred cycles each, 8 per lane per tile) are skipped
+        const bool batched = p.c_rpb <= (int64_t)p.M;
+        // fp16 outputs: 16-byte stores (8 consecutive columns per lane after a row exchange) when the groups pair up
+        const bool wide = !p.c_f32 && (NI % 2 == 0) && (p.N & 15) == 0 && (p.ldc & 7) == 0;
+        // The residual (usually C itself: x += ...) of row group j + 1 is requested BEFORE row group j is stored: behind the
+        // stores the compiler has to assume they alias, and every row group paid a full memory round trip with nothing else
+        // resident on the CU to hide it (encoder out-projection / MLP-2: +17 us per 256x256 tile, round 3).
+        bool mok_n;
+        int64_t mr_n, crow_n;
+        floatx4 res_n[NI];
+        auto rows = [&](int j, bool& mok, int64_t& mr, int64_t& crow) {
+            const int64_t m = mrow0 + j * 16 + (lane & 15);
+            mok = m < p.M;
+            const int64_t mc = mok ? m : p.M - 1;
+            const int64_t mb = batched ? mc / p.c_rpb : 0;
+            mr = batched ? mc % p.c_rpb : mc;
+            crow = mb * p.c_brows + mr + p.c_roff;
+        };
+        auto fetch = [&](int j) {
+            rows(j, mok_n, mr_n, crow_n);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int n = ncol0 + i * 16;
+                res_n[i] = (p.residual && mok_n && n < p.N) ? *reinterpret_cast<const floatx4*>(p.residual + crow_n * p.ldc + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        if (PF) fetch(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t m = mrow0 + j * 16 + (lane & 15);
-            const bool mok = m < p.M;
-            const int64_t mc = mok ? m : p.M - 1;
-            // rows are batched only for the conv outputs; elsewhere c_rpb is "infinite" and the 64-bit division and modulo
-            // (software routines of a few hundred cycles each, 8 per lane per tile) are skipped
-            const bool batched = p.c_rpb <= (int64_t)p.M;
-            const int64_t mb = batched ? mc / p.c_rpb : 0, mr = batched ? mc % p.c_rpb : mc;
-            const int64_t crow = mb * p.c_brows + mr + p.c_roff;
-            floatx4 pos4[NI], res4[NI];
+            if (!PF) fetch(j);
+            const bool mok = mok_n;
+            const int64_t mr = mr_n, crow = crow_n;
+            floatx4 res4[NI], v4[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) res4[i] = res_n[i];
+            if (PF && j + 1 < 4) fetch(j + 1);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int n = ncol0 + i * 16;
-                const bool ok = mok && n < p.N;
-                pos4[i] = (p.posemb && ok) ? *reinterpret_cast<const floatx4*>(p.posemb + mr * p.N + n) : floatx4{0.f, 0.f, 0.f, 0.f};
-                res4[i] = (p.residual && ok) ? *reinterpret_cast<const floatx4*>(p.residual + crow * p.ldc + n) : floatx4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int n = ncol0 + i * 16;
-                if (!(mok && n < p.N)) continue;
                 floatx4 v = acc[i][j] + bias4[i];
                 if (n < p.scale_n_end) v *= p.scale;  // scale_n_end is a multiple of 4
                 if (p.act) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
                 }
-                v += pos4[i];
-                v += res4[i];
+                if (p.posemb && mok && n < p.N) v += *reinterpret_cast<const floatx4*>(p.posemb + mr * p.N + n);
+                v4[i] = v + res4[i];
+            }
+            if (wide) {
+#pragma unroll
+                for (int i = 0; i + 1 < NI; i += 2) {
+                    const uint4 w = epi_pair16(v4[i], v4[i + 1]);  // every lane takes part in the exchange
+                    const int n = ncolw + 16 * (i + (q16 & 1)) + 8 * (q16 >> 1);
+                    if (mok && n < p.N)
+                        *reinterpret_cast<uint4*>(reinterpret_cast<half_t*>(p.c) + (p.c_packed ? pa_off((int)crow, n, p.N >> 5) : crow * p.ldc + n)) = w;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int n = ncol0 + i * 16;
+                if (!(mok && n < p.N)) continue;
+                const floatx4 v = v4[i];
                 if (p.c_f32) *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.c) + crow * p.ldc + n) = v;
                 else *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.c) + (p.c_packed ? pa_off((int)crow, n, p.N >> 5) : crow * p.ldc + n)) =
                         half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
@@ -355,7 +411,9 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
 #endif
     // Split-K slabs of full tiles: transpose the 128x128 fp32 tile through LDS (the operand ring is free now) so that every
     // store instruction writes two whole 512-byte rows instead of 16 separate 64-byte pieces.
-    if (p.ksplit > 1 && m0 + 128 <= p.M && n0 + 128 <= p.N && (p.ldc & 3) == 0) {
+    // (the last row tile may reach past M when the slab has the rows: slabs are padded to the consumer's row stride, and an
+    // output row depends on its own activation row only)
+    if (p.ksplit > 1 && (int64_t)(m0 + 128) * p.ldc <= p.slab_stride && n0 + 128 <= p.N && (p.ldc & 3) == 0) {
         float* tile = reinterpret_cast<float*>(&lds[0][0][0][0]);  // [128][128] fp32 = 64 KiB
         // chunk swizzle: 16-byte chunk c of row r is kept at chunk c ^ (r & 7) (writes and reads spread over the banks)
 #pragma unroll
@@ -377,7 +435,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
         }
         return;
     }
-    gemm_epilogue(p, acc, (int64_t)m0 + wx * 64, n0 + wy * 64, lane);
+    gemm_epilogue<4, !APACKED>(p, acc, (int64_t)m0 + wx * 64, n0 + wy * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------ ring GEMM (decode-step shapes)
@@ -487,7 +545,7 @@ __global__ __launch_bounds__(64 * (NC + NL)) void gemm_f16_ring_kernel(const Gem
         }
     }
     // every wave is past the last barrier of the loop: the ring is free
-    if (NC == 4 && p.ksplit > 1 && m0 + 128 <= p.M && n0 + 128 <= p.N && (p.ldc & 3) == 0) {
+    if (NC == 4 && p.ksplit > 1 && (int64_t)(m0 + 128) * p.ldc <= p.slab_stride && n0 + 128 <= p.N && (p.ldc & 3) == 0) {
         // split-K slab of a full tile: transposed through LDS, stored as whole 512-byte rows by all waves
         float* tile = reinterpret_cast<float*>(smem);  // [128][128] fp32 = 64 KiB
         if (wave < NC) {
@@ -645,8 +703,8 @@ __device__ __forceinline__ void pp2_tile(const GemmParams& p, const int seq, con
 #undef WRS_PP2_ISSUE
 #undef WRS_PP2_BARRIER
     const int64_t mrow = (int64_t)m0 + grp * 128 + wx * 64;
-    gemm_epilogue(p, acc0, mrow, n0 + wy * 128, lane);
-    gemm_epilogue(p, acc1, mrow, n0 + wy * 128 + 64, lane);
+    gemm_epilogue<4, true>(p, acc0, mrow, n0 + wy * 128, lane);
+    gemm_epilogue<4, true>(p, acc1, mrow, n0 + wy * 128 + 64, lane);
 }
 
 __global__ __launch_bounds__(512) void gemm_f16_pp2_kernel(const GemmParams p) {
@@ -680,8 +738,8 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     p.c_rpb = e.c_rows_per_batch; p.c_brows = e.c_batch_rows; p.c_roff = e.c_row_off; p.c_packed = e.c_packed;
     p.qkv_d_model = e.qkv_d_model; p.kcache = e.kcache; p.vcache = e.vcache; p.cache_row_stride = e.cache_row_stride; p.sp = e.sp;
     if (e.qkv_d_model > 0)
-        WRS_REQUIRE(N == 3 * (int64_t)e.qkv_d_model && e.qkv_d_model % 64 == 0 && e.c && !e.c_f32 && !e.c_packed && e.ldc >= e.qkv_d_model && e.ldc % 4 == 0 &&
-                        e.kcache && e.vcache && e.sp && e.cache_row_stride >= e.qkv_d_model && e.ksplit <= 1 && !e.residual && !e.posemb && !e.act &&
+        WRS_REQUIRE(N == 3 * (int64_t)e.qkv_d_model && e.qkv_d_model % 64 == 0 && e.c && !e.c_f32 && !e.c_packed && e.ldc >= e.qkv_d_model && e.ldc % 8 == 0 &&
+                        e.kcache && e.vcache && e.sp && e.cache_row_stride >= e.qkv_d_model && e.cache_row_stride % 8 == 0 && e.ksplit <= 1 && !e.residual && !e.posemb && !e.act &&
                         e.scale_n_end % 4 == 0, "gemm_f16: bad QKV epilogue");
     if (e.c_packed) WRS_REQUIRE(!e.c_f32 && N % 32 == 0 && e.ldc % 4 == 0, "gemm_f16: packed output needs fp16 and N %% 32 == 0");
     const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);

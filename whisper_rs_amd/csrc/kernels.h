@@ -10,9 +10,15 @@ namespace wrs {
 // erf-based GELU (reference model.rs:225-232, `gelu("none")`).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
 // fp32 round-off level; the result is stored as fp16): a third of the instructions of libm's erff, which cost the MLP-1
 // epilogue more than its k-loop at decode-step sizes (64 values per lane).
+// The reciprocal is v_rcp_f32 (1 ulp; the argument is in [1, inf)): `__frcp_rn` expands to the 11-instruction IEEE
+// division sequence, a third of the whole function (ISA of the MLP-1 epilogue, round 3).
 __device__ __forceinline__ float gelu_exact(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
+#ifdef WRS_GELU_IEEE_RCP
     const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+#else
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+#endif
     float poly = fmaf(t, 1.061405429f, -1.453152027f);
     poly = fmaf(t, poly, 1.421413741f);
     poly = fmaf(t, poly, -0.284496736f);
