@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void pack_kv_kernel(const half_t* __restrict__
         const int kt = kb * 2 + (f >> 1), ks = f & 1;
         const int key = kt * 16 + (l & 15);
         half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (key < T) v = *reinterpret_cast<const half8*>(src + ((int64_t)b * T + key) * ld + k_off + h * 64 + ks * 32 + 8 * (l >> 4));
+        if (key < T) v = ld_stream(reinterpret_cast<const half8*>(src + ((int64_t)b * T + key) * ld + k_off + h * 64 + ks * 32 + 8 * (l >> 4)));
         *reinterpret_cast<half8*>(kp + head_base + ((int64_t)(kt * 2 + ks) * 64 + l) * 8) = v;
     }
     // V: stage [32 keys][64 dims] in LDS
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void pack_kv_kernel(const half_t* __restrict__
         const int key_l = tid >> 3, c = tid & 7;
         const int key = kb * 32 + key_l;
         half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (key < T) v = *reinterpret_cast<const half8*>(src + ((int64_t)b * T + key) * ld + v_off + h * 64 + c * 8);
+        if (key < T) v = ld_stream(reinterpret_cast<const half8*>(src + ((int64_t)b * T + key) * ld + v_off + h * 64 + c * 8));
 #pragma unroll
         for (int j = 0; j < 8; ++j) vt[key_l][c * 8 + j] = v[j];
     }
@@ -634,8 +634,8 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
                 // 32-bit byte offset from the (wave-uniform) cache base: one v_mad_u32_u24 + add per load instead of 64-bit
                 // pointer arithmetic (a layer's cache is < 4 GiB: checked by the launcher)
                 const unsigned boff = (unsigned)anc_s[pos] * row_stride_b + (unsigned)pos * (unsigned)(D * 2) + (unsigned)(col * 2);
-                kv[u] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.kc) + boff);
-                vv[u] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.vc) + boff);
+                kv[u] = ld_stream(reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.kc) + boff));
+                vv[u] = ld_stream(reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.vc) + boff));
             }
         }
         float t[4];

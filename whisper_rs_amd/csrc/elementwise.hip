@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
-        v[i] = c < D ? *reinterpret_cast<const floatx4*>(x + row * D + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+        v[i] = c < D ? ld_stream(reinterpret_cast<const floatx4*>(x + row * D + c)) : floatx4{0.f, 0.f, 0.f, 0.f};
     }
     ln_row<NV>(v, D, lane, g, b, out16 ? out16 + row * D : nullptr, out32 ? out32 + row * D : nullptr);
 }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void layernorm_packed_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
-        v[i] = c < D ? *reinterpret_cast<const floatx4*>(x + (int64_t)row * D + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+        v[i] = c < D ? ld_stream(reinterpret_cast<const floatx4*>(x + (int64_t)row * D + c)) : floatx4{0.f, 0.f, 0.f, 0.f};
     }
     ln_row<NV>(v, D, lane, g, b, xn, nullptr, row);  // packed activation order
 }
@@ -183,6 +183,8 @@ __global__ __launch_bounds__(NT) void finish_residual_ln_kernel(float* __restric
         const int c = (i * NT + tid) * 4;
         v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
         if (c < D) {
+            // (plain loads: the slabs were written by the kernel before and x by the finish kernel before that; the
+            // non-temporal form measured 9.8 us against 9.1 us per launch here, profiles/r03_streaming_loads_ab.log)
             floatx4 acc = *reinterpret_cast<const floatx4*>(slab + (int64_t)row * D + c);
             for (int sidx = 1; sidx < ksplit; ++sidx)
                 acc += *reinterpret_cast<const floatx4*>(slab + ((int64_t)sidx * m_pad + row) * D + c);

@@ -98,6 +98,14 @@ void launch_f16_to_f32(const half_t* in, float* out, int64_t n, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------ big GEMM
+// cache-policy bits of the tiled kernels' direct-to-LDS operand loads (0 default, 1 sc0, 2 nt, 16 sc1 = L1 bypass): experiment
+// switches of scripts/micro/gemm_f16_bench (profiles/r03_glds_cache_policy.log)
+#ifndef WRS_GLDS_AUX_A
+#define WRS_GLDS_AUX_A 0
+#endif
+#ifndef WRS_GLDS_AUX_W
+#define WRS_GLDS_AUX_W 0
+#endif
 struct GemmParams {
     const half_t* a;
     int64_t lda, a_rpb, a_bs;
@@ -219,7 +227,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int n = ncol0 + i * 16;
-                res_n[i] = (p.residual && mok_n && n < p.N) ? *reinterpret_cast<const floatx4*>(p.residual + crow_n * p.ldc + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+                res_n[i] = (p.residual && mok_n && n < p.N) ? ld_stream(reinterpret_cast<const floatx4*>(p.residual + crow_n * p.ldc + n)) : floatx4{0.f, 0.f, 0.f, 0.f};
             }
         };
         if (PF) fetch(0);
@@ -353,9 +361,9 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
     do {                                                                                                                       \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[j] + (int64_t)(kt_) * (APACKED ? 1024 : 64)),  \
-                                             (__attribute__((address_space(3))) void*)&lds[buf_][0][wave * 4 + j][0], 16, 0, 0); \
+                                             (__attribute__((address_space(3))) void*)&lds[buf_][0][wave * 4 + j][0], 16, 0, WRS_GLDS_AUX_A); \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[j] + (int64_t)(kt_) * 1024), \
-                                             (__attribute__((address_space(3))) void*)&lds[buf_][1][wave * 4 + j][0], 16, 0, 0); \
+                                             (__attribute__((address_space(3))) void*)&lds[buf_][1][wave * 4 + j][0], 16, 0, WRS_GLDS_AUX_W); \
         }                                                                                                                      \
     } while (0)
     WRS_STAGE(0, kt0);
@@ -492,11 +500,11 @@ __global__ __launch_bounds__(64 * (NC + NL)) void gemm_f16_ring_kernel(const Gem
 #pragma unroll
             for (int j = 0; j < APL; ++j)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[j] + (int64_t)(kt0 + u) * 1024),
-                                                 (__attribute__((address_space(3))) void*)(st_ + (lw * APL + j) * 64), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(st_ + (lw * APL + j) * 64), 16, 0, WRS_GLDS_AUX_A);
 #pragma unroll
             for (int j = 0; j < WPL; ++j)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[j] + (int64_t)(kt0 + u) * 1024),
-                                                 (__attribute__((address_space(3))) void*)(st_ + 1024 + (lw * WPL + j) * 64), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(st_ + 1024 + (lw * WPL + j) * 64), 16, 0, WRS_GLDS_AUX_W);
         };
         static_assert(APL + WPL == 4 || APL + WPL == 12, "vmcnt immediates below");
 #define WRS_RING_KEEP_ONE() do { if (APL + WPL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); } while (0)
@@ -630,10 +638,10 @@ __device__ __forceinline__ void pp2_tile(const GemmParams& p, const int seq, con
         half8* st_ = smem + ((u_) & 3) * STAGE;                                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                          \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[j] + (int64_t)(kt0 + (u_)) * 32), \
-                                             (__attribute__((address_space(3))) void*)(st_ + (wave * 2 + j) * 64), 16, 0, 0);  \
+                                             (__attribute__((address_space(3))) void*)(st_ + (wave * 2 + j) * 64), 16, 0, WRS_GLDS_AUX_A);  \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                          \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[j] + (int64_t)(kt0 + (u_)) * 512), \
-                                             (__attribute__((address_space(3))) void*)(st_ + 1024 + (wave * 2 + j) * 64), 16, 0, 0); \
+                                             (__attribute__((address_space(3))) void*)(st_ + 1024 + (wave * 2 + j) * 64), 16, 0, WRS_GLDS_AUX_W); \
     } while (0)
 #define WRS_PP2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 

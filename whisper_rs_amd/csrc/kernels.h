@@ -28,6 +28,24 @@ __device__ __forceinline__ float gelu_exact(float x) {
 }
 #endif
 
+// Load of data the kernel reads ONCE (split-K slabs, the residual stream, logits, K/V rows of one (row, head)): the
+// non-temporal hint makes the load bypass the CU's L1, whose miss handling — not the bytes — bounded the gathers of the
+// decode self-attention (profiles/r03_self_attention_nontemporal.log).  Never for operands other workgroups of the CU or
+// XCD re-read (weights, bias vectors, LayerNorm weights).  -DWRS_NT_STREAMS=0 builds the plain loads for comparison.
+#ifndef WRS_NT_STREAMS
+#define WRS_NT_STREAMS 1
+#endif
+#ifdef __HIPCC__
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* ptr) {
+#if WRS_NT_STREAMS
+    return __builtin_nontemporal_load(ptr);
+#else
+    return *ptr;
+#endif
+}
+#endif
+
 // per-step scalars that live in device memory so that one captured hipGraph serves every step
 struct StepParams {
     int cache_pos;       // self-attention K/V slot written by this step (= tokens so far - 1)

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
     for (int v0 = v_begin + tid * 4; v0 < v_end; v0 += 1024) {
         float val4[4];
         if (vec_ok && v0 + 4 <= p.ld) {
-            const floatx4 t = *reinterpret_cast<const floatx4*>(x + v0);
+            const floatx4 t = ld_stream(reinterpret_cast<const floatx4*>(x + v0));  // a row's logits are read once
             val4[0] = t[0]; val4[1] = t[1]; val4[2] = t[2]; val4[3] = t[3];
         } else {
 #pragma unroll
