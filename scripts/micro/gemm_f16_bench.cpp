@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
             for (int k : {64, 128, 320, 640, 1280}) shapes.push_back({"d_k4", 4 * D, k, true, false, false, 1});
         }
         for (int ks : {1, 2, 4}) shapes.push_back({"d_DxD", D, D, true, false, false, ks});
+        shapes.push_back({"d_DxDr", D, D, true, true, false, 1});       // bias + in-place residual (no slab): launcher's choice
         shapes.push_back({"d_qkv", 3 * D, D, true, false, false, 1});
         shapes.push_back({"d_qkvd", 3 * D, D, false, false, false, -1});  // the step's own form: fp16 query + key / value rows into the cache
         shapes.push_back({"d_mlp1", 4 * D, D, false, false, true, 1});
@@ -46,7 +47,7 @@ int main(int argc, char** argv) {
         if (dec) { A.packed = 1; A.packed_rows = mp; }
         GemmEpi e; e.c = c.p; e.c_f32 = sh.f32out; e.ldc = sh.N;
         DevBuf kc, vc, spb;
-        if (sh.ksplit < 0) {  // QKV-to-cache epilogue: 32 cached positions per row, this step writes position 7
+        if (sh.ksplit == -1) {  // QKV-to-cache epilogue: 32 cached positions per row, this step writes position 7
             const int ctx = 32;
             kc.alloc((size_t)mp * ctx * D * 2); vc.alloc((size_t)mp * ctx * D * 2); spb.alloc(sizeof(StepParams));
             StepParams sp{}; sp.cache_pos = 7; sp.n_rows = (int)M;
