@@ -247,10 +247,14 @@ def main():
                     "is not meaningful while several lanes share the GPU, so no roofline object is reported")
     ap.add_argument("--no-overlap", action="store_true", help="sequential passes: do not queue the next step's mel/encoder/cross-K/V on the side stream while this step decodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-lib", action="store_true", help="load libwrs_mi355x_debug.so (honours the WRS_* experiment switches) instead of the product library")
     ap.add_argument("--no-shard-check", action="store_true", help="N > 1: skip rank 0's re-decode of another rank's windows (one extra pass after the timed region)")
     ap.add_argument("--stage-profile", action="store_true", help="extra eager pass with per-kernel HIP-event timing (stderr)")
     ap.add_argument("--cross-stride", type=int, default=8, help="sample every n-th layer's cross-attention launch for the roofline")
     args = ap.parse_args()
+    # the benchmark runs the PRODUCT library (no test hooks, no experiment switches); --debug-lib loads the test build, whose
+    # environment switches select the measured-and-not-kept variants (A/B runs of scripts/r03_batch*.sh)
+    os.environ["WRS_DEBUG_LIB"] = "1" if args.debug_lib else "0"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -425,6 +429,7 @@ def main():
             "transcript": {"windows": n_windows, "tokens": int(sum(len(t) for t in transcript)), "gathered_by": "window index, rank 0",
                            "other_rank_windows_equal_rank0_decode": shard_check},
             "hbm_free_gb_after_run": round(torch.cuda.mem_get_info(dev)[0] / 1e9, 1),
+            "library": os.path.basename(W._lib.LIB_PATH),
         }
         if want_cpu:
             line["cpu_baseline"] = cpu_baseline(dims, weights, audio_host[0], outs[0].tokens, args.beam, args.sample_len)

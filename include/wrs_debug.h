@@ -1,6 +1,8 @@
 /*
- * wrs_debug.h — test hooks of libwrs_mi355x.so.  NOT part of the drop-in boundary (include/wrs.h): nothing here has a
- * counterpart in laptou/whisper-rs.  They exist so that tests/ can (a) drive single kernels of the hot path on caller
+ * wrs_debug.h — test hooks.  NOT part of the drop-in boundary (include/wrs.h) and NOT exported by the product library
+ * libwrs_mi355x.so: they are linked into libwrs_mi355x_debug.so only (the product's objects + csrc/debug_api.cpp), the build
+ * tests/ and __graft_entry__.smoke() load; that build also honours the WRS_* experiment switches (csrc/common.h: exp_env),
+ * which the product library ignores.  Nothing here has a counterpart in laptou/whisper-rs.  They exist so that tests/ can (a) drive single kernels of the hot path on caller
  * data at the benchmark's shapes and compare them with an independent fp32 product, (b) make the device follow the
  * oracle's beam decisions (teacher forcing / re-synchronisation after a near-tie), and (c) exercise the host sequencer
  * and the long-form bookkeeping without a device.
@@ -134,7 +136,7 @@ int wrs_debug_transcribe_bookkeeping(int32_t ts_begin, int64_t n_audio_ctxs, int
 /* f32 PARITY MODE (csrc/parity_f32.hip): every weight, activation, K/V cache entry and product of the model in fp32
  * (v_mfma_f32_16x16x4_f32 GEMMs, fp32 attention).  Exists to demonstrate "token ids bit-exact": in this mode the
  * free-running decode must reproduce the fp32 oracle's ids and beam sources to the last step.  Slow, small models only;
- * choose before wrs_model_finalize (also: environment WRS_PARITY_F32=1 at wrs_model_create). */
+ * choose before wrs_model_finalize. */
 int wrs_debug_model_set_parity_f32(wrs_model* m, int enabled);
 /* which forms of Model::decoder_step this model has taken since it was created (OR; steps replayed from a captured graph
  * count through their capture): bit 0 tiled GEMMs (>= dec_big_gemm_rows rows), 1 persistent ring GEMMs

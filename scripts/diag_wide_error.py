@@ -6,6 +6,8 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import os
+os.environ.setdefault("WRS_DEBUG_LIB", "1")  # test build: include/wrs_debug.h hooks + experiment switches
 import whisper_rs_amd as W
 from whisper_rs_amd import debug as DBG
 from whisper_rs_amd.consts import MODEL_DIMS, TokenIds

@@ -1,6 +1,8 @@
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch
+import os
+os.environ.setdefault("WRS_DEBUG_LIB", "1")  # test build: include/wrs_debug.h hooks + experiment switches
 import whisper_rs_amd as W
 from helpers import gpu_model, oracle_model, oracle_ids, oracle_decode_options, mel_windows
 from oracle import decode as OD

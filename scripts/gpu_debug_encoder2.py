@@ -1,6 +1,8 @@
 import sys, os, ctypes as C
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch, torch.nn.functional as F
+import os
+os.environ.setdefault("WRS_DEBUG_LIB", "1")  # test build: include/wrs_debug.h hooks + experiment switches
 import whisper_rs_amd as W
 from whisper_rs_amd import synth, _lib
 from whisper_rs_amd.consts import ModelDims

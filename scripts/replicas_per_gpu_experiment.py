@@ -3,6 +3,8 @@ overlap one replica's MFMA-bound encoder with the other's HBM-bound decode steps
 import os, sys, threading, time
 sys.path.insert(0, os.getcwd())
 import torch
+import os
+os.environ.setdefault("WRS_DEBUG_LIB", "1")  # test build: include/wrs_debug.h hooks + experiment switches
 import whisper_rs_amd as W
 from whisper_rs_amd import synth
 from bench import make_weights_device

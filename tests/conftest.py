@@ -2,6 +2,9 @@ import os
 import sys
 import dataclasses
 
+# tests drive the library through the test hooks of include/wrs_debug.h: load the test build (the product's objects + debug_api.cpp)
+os.environ["WRS_DEBUG_LIB"] = "1"
+
 import numpy as np
 import pytest
 

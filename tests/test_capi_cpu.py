@@ -24,8 +24,24 @@ def test_library_exports_every_declared_symbol():
     names = _declared_symbols()
     assert len(names) >= 30
     for n in names:
-        assert hasattr(lib, n), f"{n} is declared in include/wrs.h but not exported by libwrs_mi355x.so"
+        assert hasattr(lib, n), f"{n} is declared in include/wrs.h but not exported by {L.LIB_PATH}"
     assert set(L.SYMBOLS) == set(names), set(L.SYMBOLS) ^ set(names)
+
+
+def test_product_library_is_the_boundary_and_nothing_else():
+    """libwrs_mi355x.so (what a caller links: bench.py, examples/transcribe, the Rust crate) exports every entry of
+    include/wrs.h and NOT ONE test hook of include/wrs_debug.h; the hooks live in libwrs_mi355x_debug.so (the same
+    objects + csrc/debug_api.cpp), which is what this test session has loaded."""
+    import ctypes
+    assert L.IS_DEBUG_LIB and L.LIB_PATH == L.DEBUG_LIB_PATH, "tests/conftest.py selects the test build"
+    product = ctypes.CDLL(L.PRODUCT_LIB_PATH)
+    for n in _declared_symbols():
+        assert hasattr(product, n), f"{n} is declared in include/wrs.h but not exported by libwrs_mi355x.so"
+    leaked = [n for n in _declared_symbols("wrs_debug.h") if hasattr(product, n)]
+    assert not leaked, f"test hooks exported by the product library: {leaked}"
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", L.PRODUCT_LIB_PATH], capture_output=True, text=True).stdout
+    assert "wrs_debug_" not in out, "a wrs_debug_* symbol is defined in the product library"
 
 
 def test_library_exports_every_debug_symbol():
@@ -35,7 +51,7 @@ def test_library_exports_every_debug_symbol():
     names = _declared_symbols("wrs_debug.h")
     assert len(names) >= 8
     for n in names:
-        assert hasattr(lib, n), f"{n} is declared in include/wrs_debug.h but not exported by libwrs_mi355x.so"
+        assert hasattr(lib, n), f"{n} is declared in include/wrs_debug.h but not exported by libwrs_mi355x_debug.so"
     assert set(DBG.SYMBOLS) == set(names), set(DBG.SYMBOLS) ^ set(names)
     assert not (set(names) & set(_declared_symbols())), "a debug hook leaked into the boundary header"
 

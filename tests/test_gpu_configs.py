@@ -47,16 +47,31 @@ def test_config1_tiny_en_greedy_wav_file(gpu, tmp_path):
         prompt=gpu.TranscribePrompt.None_(True)))               # examples/transcribe.rs:58-60
     got = gt.run(samples)
     gt.close()
-    assert [w_[0] for w_ in got.windows] == [w_[0] for w_ in want.windows], "seek sequence differs"
-    if not np.array_equal(got.tokens, want.tokens.numpy()):
-        # greedy argmax near-tie: show it with the window-level machinery (margin recorded), then require equality after resync
+    seeks_equal = [w_[0] for w_ in got.windows] == [w_[0] for w_ in want.windows]
+    if not (seeks_equal and np.array_equal(got.tokens, want.tokens.numpy())):
+        # A free-running greedy decode: ONE near-tie argmax (fp16 products against the fp32 oracle) changes every later token and,
+        # through the timestamps, the seek sequence (seen in round 3: a 1-ulp change of the GELU's reciprocal moved window 0's
+        # last timestamp from 1980 to 658).  Both loops start at window 0 with no prompt, so the window-level machinery shows the
+        # first divergence there: P.run_with_resync raises unless it is a near-tie priced in the ORACLE's own scores, and requires
+        # the device to follow the oracle to the last step once re-synchronised.
+        # Each side decodes ITS OWN log-mel, as the two loops did (they agree to 1e-3, test_gpu_mel.py): the candidate errors
+        # measured in this run — which bound the accepted margin — then include what the spectrogram difference does to the scores.
         from oracle import audio as OA
-        mel = OA.log_mel_spectrogram(torch.from_numpy(samples), OA.mel_filter()).numpy()[None]
-        view, _ = _oracle_run("tiny.en", mel, oracle_decode_options(sample_len=sample_len, beam_size=None))
+        omel = OA.log_mel_spectrogram(torch.from_numpy(samples), OA.mel_filter()).numpy()[None]
+        gmel = gpu.audio.log_mel_spectrogram(samples[None])
+        assert np.abs(gmel - omel).max() < 1e-3
+        view, _ = _oracle_run("tiny.en", omel, oracle_decode_options(sample_len=sample_len, beam_size=None))
         task = gpu.DecodeTask(gpu_model(gpu, "tiny.en"), TokenIds.english(), gpu.DecodeOptions(sample_len=sample_len, token_extract_mode=gpu.TokenExtractMode.Greedy()))
-        splits = _free_run("config1_tiny_en_greedy", task, mel, view, 1)
+        splits = _free_run("config1_tiny_en_greedy", task, gmel, view, 1)
         task.close()
-        assert splits, "transcribe tokens differ from the oracle but the window decode shows no near-tie"
+        assert splits, "transcribe output differs from the oracle but the decode of window 0 shows no near-tie"
+        # the loop's own bookkeeping on the device's windows (transcribe.rs:151-234; bit-exact against the oracle on scripted
+        # windows in test_host_logic_cpu.py): seeks strictly increase inside the recording, every segment belongs to a window
+        seeks = [w_[0] for w_ in got.windows]
+        assert seeks[0] == 0 and all(b > a for a, b in zip(seeks, seeks[1:])) and seeks[-1] < 3000
+        # (segment times are window offset + timestamp * 0.02 s; the reference's timestamp rules do not order a pair, timestamp_tokens.rs:47-78)
+        assert all(sg.seek in seeks and min(sg.start_time, sg.end_time) >= sg.seek * 0.01 - 1e-9 for sg in got.segments)
+        print(f"config 1: explained near-tie split(s) {[(r['step'], round(r['margin'], 5)) for r in splits]}")
     else:
         assert len(got.segments) == len(want.segments)
         for g, o in zip(got.segments, want.segments):

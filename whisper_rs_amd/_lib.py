@@ -4,7 +4,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwrs_mi355x.so")
+PRODUCT_LIB_PATH = os.path.join(_HERE, "libwrs_mi355x.so")
+DEBUG_LIB_PATH = os.path.join(_HERE, "libwrs_mi355x_debug.so")
+# WRS_DEBUG_LIB=1 (set by tests/conftest.py and __graft_entry__.smoke() before this module is imported) selects the test build:
+# the product's objects + the include/wrs_debug.h hooks, with the experiment switches honoured.  One library per process.
+IS_DEBUG_LIB = os.environ.get("WRS_DEBUG_LIB", "0") == "1"
+LIB_PATH = DEBUG_LIB_PATH if IS_DEBUG_LIB else PRODUCT_LIB_PATH
 
 WRS_OK, WRS_EINVAL, WRS_ENODEVICE, WRS_EHIP, WRS_ESTATE, WRS_EUNSUPPORTED = 0, 1, 2, 3, 4, 5
 WRS_F32, WRS_F16 = 0, 1

@@ -482,8 +482,8 @@ void launch_attn_full(const half_t* q, int64_t ldq, const half_t* kp, const half
     WRS_REQUIRE(!causal || Tq == T, "attn_full: causal attention needs as many keys as queries");
     AttnParams p{q, ldq, kp, vp, T, (int)round_up(T, 32), H, Tq, 0, out, ldo, nullptr, 0, 0, nullptr, 1.f, n_batch * H, causal ? 1 : 0};
     const int64_t units8 = cdiv((int64_t)n_batch * H, 8);
-    static const int nq = getenv("WRS_ATTN_NQ") ? atoi(getenv("WRS_ATTN_NQ")) : ENC_ATTN_NQ;
-    static const int lds_mode = getenv("WRS_ATTN_LDS") ? atoi(getenv("WRS_ATTN_LDS")) : 2;  // 0: per-wave K/V streams (round 1); 1/2/4: LDS-shared, NQ tiles per wave
+    static const int nq = exp_env("WRS_ATTN_NQ") ? atoi(exp_env("WRS_ATTN_NQ")) : ENC_ATTN_NQ;
+    static const int lds_mode = exp_env("WRS_ATTN_LDS") ? atoi(exp_env("WRS_ATTN_LDS")) : 2;  // 0: per-wave K/V streams (round 1); 1/2/4: LDS-shared, NQ tiles per wave
     if (lds_mode == 4) { attn_enc_kernel<4><<<(unsigned)(8 * units8 * cdiv(Tq, 512)), 512, 0, s>>>(p); return; }
     if (lds_mode == 2) { attn_enc_kernel<2><<<(unsigned)(8 * units8 * cdiv(Tq, 256)), 512, 0, s>>>(p); return; }
     if (lds_mode == 1) { attn_enc_kernel<1><<<(unsigned)(8 * units8 * cdiv(Tq, 128)), 512, 0, s>>>(p); return; }

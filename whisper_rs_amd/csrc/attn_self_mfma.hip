@@ -362,9 +362,12 @@ __global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParam
 // Non-temporal K / V loads (they bypass the CU's L1: every row is used once, by one wave): 65.2 -> 50.6 us on the kernel
 // test's shapes (profiles/r03_self_attention_nontemporal.log).  The PMC comparison of round 2 had shown the texture-address
 // unit stalled by the L1 70x more often than in a loads-only kernel of the same address pattern; this is that stall.
-// WRS_SELF_NT=0 (read once per process) selects the plain loads for comparison.
+// In the decode step (colder caches than the kernel test) the gain is 74.9 -> 71.9 us (profiles/r03_insitu_ab_start_vs_epilogues.log).
+// A fragment-order gather with these loads (K rows straight into MFMA operands, no K image in LDS) was 101 us against 71.8 us
+// in situ (profiles/r03_self_attention_fragment_order.log): not kept.
+// WRS_SELF_NT=0 (test build, read once per process) selects the plain loads for comparison.
 static bool self_mfma_nt() {
-    static const bool nt = !(getenv("WRS_SELF_NT") && getenv("WRS_SELF_NT")[0] == '0');
+    static const bool nt = !(exp_env("WRS_SELF_NT") && exp_env("WRS_SELF_NT")[0] == '0');
     return nt;
 }
 

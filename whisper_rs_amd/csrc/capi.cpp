@@ -47,7 +47,6 @@ int wrs_model_create(const wrs_model_dims* dims, int device_id, wrs_model** out)
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         HIP_CHECK(hipStreamCreateWithPriority(&h->m.stream, hipStreamNonBlocking, prio_greatest));
         h->m.timer = new StageTimer();
-        if (const char* e = getenv("WRS_PARITY_F32")) h->m.parity_f32 = e[0] == '1';  // test aid, see include/wrs_debug.h
         h->m.read_switches();
         *out = h.release();
     });

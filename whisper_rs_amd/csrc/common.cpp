@@ -24,4 +24,7 @@ void require_device(int device_id) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         WRS_THROW(WRS_ENODEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
 }
+bool g_experiment_switches = false;
+const char* exp_env(const char* name) { return g_experiment_switches ? getenv(name) : nullptr; }
+
 }  // namespace wrs

@@ -132,4 +132,10 @@ static inline int64_t round_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
 
 void require_device(int device_id);  // throws WRS_ENODEVICE unless device_id is a gfx950 GPU
 
+// Experiment switches (environment variables that select a measured-and-not-kept variant, or switch a default off for an A/B run)
+// are honoured only by the TEST build of the library (libwrs_mi355x_debug.so: debug_api.cpp sets the flag when it is loaded).
+// In the product library exp_env() returns nullptr for every name: no environment variable changes what it runs.
+extern bool g_experiment_switches;
+const char* exp_env(const char* name);
+
 }  // namespace wrs

@@ -1,4 +1,5 @@
-// extern "C" test hooks of libwrs_mi355x.so (include/wrs_debug.h): not part of the drop-in boundary.
+// extern "C" test hooks (include/wrs_debug.h): not part of the drop-in boundary and NOT in the product library — this file is
+// linked into libwrs_mi355x_debug.so only (the same objects as libwrs_mi355x.so plus this one), which tests and smoke() load.
 #include "handles.h"
 #include "../../include/wrs_debug.h"
 #include <cmath>
@@ -6,6 +7,9 @@
 using namespace wrs;
 
 namespace {
+
+// loading the test build turns the library's experiment switches on (common.h: exp_env)
+const bool g_switches_on = (wrs::g_experiment_switches = true);
 
 struct DebugCtx {
     hipStream_t s = nullptr;

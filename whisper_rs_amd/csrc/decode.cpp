@@ -154,7 +154,7 @@ void DecodeTask::configure(Model* model, const wrs_token_ids& tid, const wrs_dec
     // K/V cache positions by need (prompt + sample_len), grown by ensure_ctx when a longer prompt is set: at large-v2 and 1 535
     // rows all 448 positions would take 113 GB
     m->init_state(st, max_audio, group, ctx_for(sample_begin + sample_len));
-    const char* env = getenv("WRS_NO_GRAPH");
+    const char* env = exp_env("WRS_NO_GRAPH");
     use_graph = !(env && env[0] == '1');
 }
 
@@ -447,7 +447,7 @@ void DecodeTask::prefill(int n_audio, double* no_speech_out) {
     const int k = (mode == WRS_EXTRACT_BEAM_SEARCH) ? G + 1 : 1;
     const FilterCfg cfg = filter_cfg();
     hipStream_t s = m->stream;
-    static const bool sequential_env = getenv("WRS_PREFILL_SEQUENTIAL") && getenv("WRS_PREFILL_SEQUENTIAL")[0] == '1';
+    static const bool sequential_env = exp_env("WRS_PREFILL_SEQUENTIAL") && exp_env("WRS_PREFILL_SEQUENTIAL")[0] == '1';
     auto filter_at = [&](bool want_ns) {
         StepParams* sp = st.sp_h();
         sp->cache_pos = S - 1; sp->pos_idx = S - 1; sp->parity = 0; sp->first_step = 1;

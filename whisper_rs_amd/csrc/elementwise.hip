@@ -245,7 +245,7 @@ __global__ __launch_bounds__(NT) void finish_residual_ln_kernel(float* __restric
 void launch_finish_residual_ln(float* x, const float* slab, int ksplit, int m_pad, const float* bias, const float* g,
                                const float* b, int M, int D, half_t* xn, hipStream_t s) {
     WRS_REQUIRE(D % 32 == 0 && D <= 2048, "finish_residual_ln: D=%d unsupported", D);
-    static const bool plain = getenv("WRS_FINISH_PLAIN_ROWS") && getenv("WRS_FINISH_PLAIN_ROWS")[0] == '1';  // experiment switch
+    static const bool plain = exp_env("WRS_FINISH_PLAIN_ROWS") && exp_env("WRS_FINISH_PLAIN_ROWS")[0] == '1';  // experiment switch
     const int per = (M >= 64 && !plain) ? (int)round_up(cdiv(M, 8), 8) : 0;  // rows per XCD (few rows: plain order)
     const unsigned grid = per ? 8u * (unsigned)per : (unsigned)M;
     if (D == 1280) finish_residual_ln_kernel<1, 320><<<grid, 320, 0, s>>>(x, slab, ksplit, m_pad, bias, g, b, M, D, xn, per);

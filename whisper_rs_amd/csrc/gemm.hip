@@ -759,7 +759,7 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     if (A.packed) WRS_REQUIRE(A.packed_rows >= round_up(M, 128), "gemm_f16: packed A must hold a multiple of 128 rows (%ld < %ld)", (long)A.packed_rows, (long)round_up(M, 128));
     const int force = g_gemm_force;
     // 256x256 ping-pong kernel: row-major activations, N a multiple of 256, grid fills the chip
-    static const int pp2_mode = getenv("WRS_GEMM_PP2") ? atoi(getenv("WRS_GEMM_PP2")) : 1;  // 0 off, 1 auto, 2 always
+    static const int pp2_mode = exp_env("WRS_GEMM_PP2") ? atoi(exp_env("WRS_GEMM_PP2")) : 1;  // 0 off, 1 auto, 2 always
     const int64_t pp2_tiles = cdiv(M, 256) * (N / 256);
     const bool pp2_ok = !A.packed && N % 256 == 0 && (K / 32) % p.ksplit == 0;
     if (force == GEMM_PP2) WRS_REQUIRE(pp2_ok, "gemm_f16: the 256x256 kernel needs row-major A and N %% 256 == 0");
@@ -774,7 +774,7 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     }
     const dim3 grid((unsigned)(8 * cdiv(tiles, 8)), (unsigned)p.ksplit);
     // decode-step shapes (packed activations) whose grid gives a CU at most one workgroup: loader/consumer ring kernels
-    static const int ring_mode = getenv("WRS_GEMM_RING") ? atoi(getenv("WRS_GEMM_RING")) : 1;  // 0 off, 1 auto, 2 always
+    static const int ring_mode = exp_env("WRS_GEMM_RING") ? atoi(exp_env("WRS_GEMM_RING")) : 1;  // 0 off, 1 auto, 2 always
     if (force == GEMM_RING) WRS_REQUIRE(A.packed, "gemm_f16: the ring kernel needs packed activations");
     if (A.packed && (force == GEMM_RING || (force == GEMM_AUTO && ring_mode != 0 && (tiles * p.ksplit <= 256 || (ring_mode == 2 && p.ksplit > 1))))) {
         const size_t shmem = 3 * 2048 * 16;

@@ -178,15 +178,24 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
     }
     typedef float floatx4 __attribute__((ext_vector_type(4)));
     const bool vec_ok = (p.ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.logits) & 15) == 0);
-    for (int v0 = v_begin + tid * 4; v0 < v_end; v0 += 1024) {
-        float val4[4];
-        if (vec_ok && v0 + 4 <= p.ld) {
-            const floatx4 t = ld_stream(reinterpret_cast<const floatx4*>(x + v0));  // a row's logits are read once
-            val4[0] = t[0]; val4[1] = t[1]; val4[2] = t[2]; val4[3] = t[3];
-        } else {
+    // the 4 values of a thread's iteration; three iterations are requested ahead (the loop body is a chain of data-dependent
+    // branches: the compiler keeps ONE load in flight per wave otherwise, and the pass ran at 1 TB/s)
+    auto fetch4 = [&](int v0) -> floatx4 {
+        if (v0 >= v_end) return floatx4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (vec_ok && v0 + 4 <= p.ld) return ld_stream(reinterpret_cast<const floatx4*>(x + v0));  // a row's logits are read once
+        floatx4 t;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) val4[e] = v0 + e < v_end ? x[v0 + e] : -INFINITY;
-        }
+        for (int e = 0; e < 4; ++e) t[e] = v0 + e < v_end ? x[v0 + e] : -INFINITY;
+        return t;
+    };
+    const int v_first = v_begin + tid * 4;
+    floatx4 ahead0 = fetch4(v_first), ahead1 = fetch4(v_first + 1024), ahead2 = fetch4(v_first + 2048);
+    for (int v0 = v_first; v0 < v_end; v0 += 1024) {
+        const floatx4 cur4 = ahead0;
+        ahead0 = ahead1;
+        ahead1 = ahead2;
+        ahead2 = fetch4(v0 + 3072);
+        const float val4[4] = {cur4[0], cur4[1], cur4[2], cur4[3]};
         const unsigned bits = smem[v0 >> 5] >> (v0 & 31);  // 4 consecutive ids never straddle a 32-bit word (v0 % 4 == 0)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -388,7 +397,7 @@ void launch_filter_topk(const float* logits, int n_rows, const FilterCfg& cfg, c
     p.out_lp = out_lp; p.out_id = out_id; p.no_speech_out = no_speech; p.out_filtered = out_filtered;
     const size_t shmem = (size_t)((cfg.n_vocab + 31) / 32) * 4;
     p.ws = nullptr; p.chunk = 0;
-    static const bool split_off = getenv("WRS_FILTER_SPLIT") && getenv("WRS_FILTER_SPLIT")[0] == '0';
+    static const bool split_off = exp_env("WRS_FILTER_SPLIT") && exp_env("WRS_FILTER_SPLIT")[0] == '0';
     if (cfg.ws && !out_filtered && !split_off && n_rows <= FILTER_SPLIT_MAX_ROWS && n_rows <= cfg.ws_rows && 2 * FILTER_SPLIT * k <= 256 &&
         6 + 4 * k <= FILTER_WS_STRIDE) {
         p.ws = cfg.ws;

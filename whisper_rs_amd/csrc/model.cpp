@@ -452,12 +452,12 @@ void Model::encoder_from_mel_t(int n) {
 // Experiment switches (unset = the default path).  Read ONCE per model, at creation: a decode task's captured step graph is keyed
 // on (rows, cross buffer) only, so a switch that changed under a live model would leave graph and eager steps on different paths.
 void Model::read_switches() {
-    if (const char* e = getenv("WRS_DEC_BIG_GEMM_ROWS")) dec_big_gemm_rows = atoi(e);
-    const char* e = getenv("WRS_DEC_PRING");
+    if (const char* e = exp_env("WRS_DEC_BIG_GEMM_ROWS")) dec_big_gemm_rows = atoi(e);
+    const char* e = exp_env("WRS_DEC_PRING");
     dec_slab_path = !(e && e[0] == '1');
-    e = getenv("WRS_DEC_FUSED");
+    e = exp_env("WRS_DEC_FUSED");
     dec_fused_tiny = e && e[0] == '1';
-    e = getenv("WRS_SELF_MFMA_MIN_AUDIO");
+    e = exp_env("WRS_SELF_MFMA_MIN_AUDIO");
     self_mfma_min_audio = e ? atoi(e) : 64;
 }
 
@@ -616,7 +616,7 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
     int* self_kcount = self_klist + (size_t)st.a_cap * st.self_keys_stride;
     // ... and at >= dec_big_gemm_rows rows the QKV GEMM's epilogue hands the attention kernel its operands directly (query as
     // fp16, new key / value rows appended to the cache: no fp32 slab to write and re-read; WRS_DEC_QKV_SLAB=1 keeps the slab)
-    static const bool qkv_slab_forced = getenv("WRS_DEC_QKV_SLAB") && getenv("WRS_DEC_QKV_SLAB")[0] == '1';
+    static const bool qkv_slab_forced = exp_env("WRS_DEC_QKV_SLAB") && exp_env("WRS_DEC_QKV_SLAB")[0] == '1';
     const bool qkv_direct = self_mfma && big && !qkv_slab_forced;
     step_paths_seen |= (big ? 1 : 0) | (self_mfma ? 8 : 0) | (qkv_direct ? 16 : 0);
     if (self_mfma) {

@@ -135,7 +135,7 @@ struct Model {
     std::vector<BlockW> dec;
     float *ln_g = nullptr, *ln_b = nullptr;
 
-    // f32 parity mode (parity_f32.hip; wrs_debug_model_set_parity_f32 / WRS_PARITY_F32=1 before finalize): fp32 weights,
+    // f32 parity mode (parity_f32.hip; wrs_debug_model_set_parity_f32 before finalize): fp32 weights,
     // activations, caches and products, to demonstrate bit-exact token ids against the fp32 oracle.  Test aid, slow.
     bool parity_f32 = false;
     float *conv1_w32 = nullptr, *conv2_w32 = nullptr, *emb32 = nullptr;

@@ -1,4 +1,4 @@
-// f32 PARITY MODE (wrs_model_set_parity_mode / WRS_PARITY_F32=1): the same hot path with every activation, weight,
+// f32 PARITY MODE (wrs_debug_model_set_parity_f32, test build only): the same hot path with every activation, weight,
 // K/V cache entry and product in fp32 (v_mfma_f32_16x16x4_f32 GEMMs, fp32 attention).  It exists to DEMONSTRATE the
 // north-star's "token-id outputs bit-exact": in this mode the free-running beam search must reproduce the fp32 CPU oracle's
 // token ids and source indices to the last step in every golden case (tests/test_gpu_parity_f32.py), which shows that

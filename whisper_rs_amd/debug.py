@@ -66,6 +66,9 @@ _bound = False
 
 def lib():
     global _bound
+    if not L.IS_DEBUG_LIB:
+        raise ImportError("the include/wrs_debug.h hooks live in libwrs_mi355x_debug.so only: set WRS_DEBUG_LIB=1 before importing "
+                          "whisper_rs_amd (tests/conftest.py and __graft_entry__.smoke() do)")
     l = L.load()
     if not _bound:
         for name, (res, args) in SYMBOLS.items():
