@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 batch 9: work-stealing self-attention (units handed out by a counter to a grid of resident waves): tests, kernel test and in situ A/B
 set -o pipefail
-out=gpurun_out/r03j
+out=gpurun_out/r03k
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout -k 10 600 python3 -m pytest tests/test_gpu_attention.py tests/test_gpu_filters.py tests/test_gpu_decode.py tests/test_gpu_model.py tests/test_gpu_wide.py tests/test_gpu_golden.py -x -q > $out/pytest_subset.log 2>&1 || { tail -30 $out/pytest_subset.log; exit 1; }
@@ -16,7 +16,7 @@ prof() {  # $1 tag
   rocprofv3 --kernel-trace --output-format csv -d $out/prof_$1 -o t -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --no-shard-check --debug-lib > $out/bench_$1.json.log 2>&1 || { tail -5 $out/bench_$1.json.log; return 1; }
   python3 scripts/trace_summary.py $(find $out/prof_$1 -name '*kernel_trace.csv' | head -1) > $out/trace_summary_$1.txt
   rm -rf $out/prof_$1
-  echo "prof $1 done"; grep -E "attn_self_mfma|attn_mfma|filter_topk" $out/trace_summary_$1.txt | head -4
+  echo "prof $1 done"; grep -E "attn_self_mfma|attn_mfma|pack_kv" $out/trace_summary_$1.txt | head -4
 }
 WRS_SELF_STEAL=1 prof steal1 || exit 1
 WRS_SELF_STEAL=0 prof steal0 || exit 1

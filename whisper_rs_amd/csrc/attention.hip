@@ -46,68 +46,52 @@ __device__ __forceinline__ float sum8(float x) {  // every lane gets the sum ove
 size_t packed_kv_halfs_per_head(int T) { return (size_t)round_up(T, 32) * 64; }
 
 // ------------------------------------------------------------------------------------------ pack
-// grid (ceil(Tp / 128), H, n_batch), 256 threads.  One block packs 4 x 32 keys of one head (one 32-key piece at a time: 288 000
-// workgroups of 8 KB each ran at 3 TB/s): K is a permuted 16-byte-chunk copy, V needs a transpose through LDS.
-static constexpr int PACK_SUB = 4;
+// grid (Tp/32, H, n_batch), 256 threads.  One block packs 32 keys of one head: K is a permuted
+// 16-byte-chunk copy, V needs a transpose through LDS.
 __global__ __launch_bounds__(256) void pack_kv_kernel(const half_t* __restrict__ src, int64_t ld, int64_t k_off,
                                                       int64_t v_off, int T, int H, half_t* __restrict__ kp,
                                                       half_t* __restrict__ vp) {
-    __shared__ _Float16 vt[2][32][64 + 8];
-    const int h = blockIdx.y, b = blockIdx.z;
+    __shared__ _Float16 vt[32][64 + 8];
+    const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x;
     const int Tp = (T + 31) / 32 * 32;
     const int64_t head_base = ((int64_t)b * H + h) * (int64_t)Tp * 64;
-    // all of the block's rows are requested first (two 16-byte loads per thread and piece)
-    half8 kv[PACK_SUB], vv[PACK_SUB];
-#pragma unroll
-    for (int sub = 0; sub < PACK_SUB; ++sub) {
-        const int kb = (int)blockIdx.x * PACK_SUB + sub;
-        kv[sub] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        vv[sub] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        {   // K: 2 key tiles x 2 ksteps x 64 lanes = 256 chunks of 16 B
-            const int l = tid & 63, f = tid >> 6;  // f = tile_in_block*2 + ks
-            const int key = (kb * 2 + (f >> 1)) * 16 + (l & 15), ks = f & 1;
-            if (key < T) kv[sub] = ld_stream(reinterpret_cast<const half8*>(src + ((int64_t)b * T + key) * ld + k_off + h * 64 + ks * 32 + 8 * (l >> 4)));
-        }
-        {   // V: [32 keys][64 dims]
-            const int key = kb * 32 + (tid >> 3), c = tid & 7;
-            if (key < T) vv[sub] = ld_stream(reinterpret_cast<const half8*>(src + ((int64_t)b * T + key) * ld + v_off + h * 64 + c * 8));
-        }
+    // K: 2 key tiles x 2 ksteps x 64 lanes = 256 chunks of 16 B
+    {
+        const int l = tid & 63, f = tid >> 6;  // f = tile_in_block*2 + ks
+        const int kt = kb * 2 + (f >> 1), ks = f & 1;
+        const int key = kt * 16 + (l & 15);
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < T) v = ld_stream(reinterpret_cast<const half8*>(src + ((int64_t)b * T + key) * ld + k_off + h * 64 + ks * 32 + 8 * (l >> 4)));
+        *reinterpret_cast<half8*>(kp + head_base + ((int64_t)(kt * 2 + ks) * 64 + l) * 8) = v;
     }
+    // V: stage [32 keys][64 dims] in LDS
+    {
+        const int key_l = tid >> 3, c = tid & 7;
+        const int key = kb * 32 + key_l;
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < T) v = ld_stream(reinterpret_cast<const half8*>(src + ((int64_t)b * T + key) * ld + v_off + h * 64 + c * 8));
 #pragma unroll
-    for (int sub = 0; sub < PACK_SUB; ++sub) {
-        const int kb = (int)blockIdx.x * PACK_SUB + sub;
-        if (kb * 32 >= Tp) break;  // block-uniform
-        {
-            const int l = tid & 63, f = tid >> 6;
-            const int kt = kb * 2 + (f >> 1), ks = f & 1;
-            *reinterpret_cast<half8*>(kp + head_base + ((int64_t)(kt * 2 + ks) * 64 + l) * 8) = kv[sub];
-        }
-        _Float16 (*img)[64 + 8] = vt[sub & 1];  // two images in turn: one barrier per piece
-        {
-            const int key_l = tid >> 3, c = tid & 7;
+        for (int j = 0; j < 8; ++j) vt[key_l][c * 8 + j] = v[j];
+    }
+    __syncthreads();
+    {
+        const int l = tid & 63, dt = tid >> 6;
+        const int q = l >> 4, d = dt * 16 + (l & 15);
+        half8 v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) img[key_l][c * 8 + j] = vv[sub][j];
+        for (int j = 0; j < 8; ++j) {
+            const int key_l = j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4);
+            v[j] = vt[key_l][d];
         }
-        __syncthreads();
-        {
-            const int l = tid & 63, dt = tid >> 6;
-            const int q = l >> 4, d = dt * 16 + (l & 15);
-            half8 v;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int key_l = j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4);
-                v[j] = img[key_l][d];
-            }
-            *reinterpret_cast<half8*>(vp + head_base + ((int64_t)(kb * 4 + dt) * 64 + l) * 8) = v;
-        }
+        *reinterpret_cast<half8*>(vp + head_base + ((int64_t)(kb * 4 + dt) * 64 + l) * 8) = v;
     }
 }
 
 void launch_pack_kv(const half_t* src, int64_t ld, int64_t k_off, int64_t v_off, int n_batch, int T, int H, half_t* kp,
                     half_t* vp, hipStream_t s) {
     WRS_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "pack_kv: alignment");
-    dim3 grid((unsigned)cdiv(cdiv(T, 32), PACK_SUB), (unsigned)H, (unsigned)n_batch);
+    dim3 grid((unsigned)cdiv(T, 32), (unsigned)H, (unsigned)n_batch);
     pack_kv_kernel<<<grid, 256, 0, s>>>(src, ld, k_off, v_off, T, H, kp, vp);
 }
 

@@ -102,13 +102,10 @@ __global__ __launch_bounds__(256) void self_keys_kernel(const int* __restrict__ 
         kcount[a] = base + (include_new ? G : 0);
         out[0] = base + (include_new ? G : 0);  // the attention kernel reads count and first entries with one round trip
     }
-    // work counters of the step's attention launches (one per layer, attn_self_mfma_kernel): behind the counts
-    if (a == 0 && tid < SELF_WORK_CTRS) kcount[gridDim.x + tid] = 0;
 }
 
 void launch_self_keys(const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_audio, int G, const StepParams* sp, int* klist,
                       int klist_stride, int* kcount, bool include_new, hipStream_t s) {
-    static_assert(SELF_WORK_CTRS <= 256, "one thread per counter");
     WRS_REQUIRE(G >= 1 && G <= 8 && n_ctx <= 512 && n_audio >= 1 && klist_stride >= G * n_ctx + 1, "self_keys: bad shape (G %d, n_ctx %d)", G, n_ctx);
     self_keys_kernel<<<n_audio, 256, 0, s>>>(anc_base, anc_buf_stride, n_ctx, G, sp, klist, klist_stride, kcount, include_new ? 1 : 0);
 }
@@ -127,9 +124,6 @@ struct SelfMfmaParams {
     int klist_stride;
     const int* kcount;
     half_t* out;         // packed activation order
-    int n_audio;
-    int* work_ctr;       // != null: (audio, head) units are handed out by this counter (zeroed by self_keys_kernel) to a grid of
-                         // resident waves; null: one wave per unit, unit = position in the grid
     const half_t* q16;   // != null: the query as fp16 [rows, D] (bias and scale applied) and the new keys / values already in the
                          // cache AND in the key list (QKV GEMM epilogue + self_keys include_new); slab / bias / scale unused
 };
@@ -158,33 +152,12 @@ __device__ __forceinline__ void slab_sum8(const float* __restrict__ slab, int ks
 
 // NT: the cached K / V rows are requested with the non-temporal hint (every row is used once per launch by one wave)
 template <bool NT>
-__global__ __launch_bounds__(256, 4) void attn_self_mfma_kernel(const SelfMfmaParams p) {
+__global__ __launch_bounds__(256) void attn_self_mfma_kernel(const SelfMfmaParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[4][SM_WAVE];
-    const int wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
-    // Units = (audio, head) pairs.  With a work counter the grid is the set of waves the chip holds at once (4 per SIMD: 124
-    // registers, 8.3 KB of LDS each) and every wave takes units until none is left: 307 audios x 20 heads = 6 140 units are 1.5
-    // "rounds" of 4 096 resident waves, and as one wave per unit the second round ran half empty — on a kernel that lives on the
-    // number of row requests in flight.  The kernel has no workgroup barrier: every wave works on its own LDS slice.
-    const int n_units = p.n_audio * p.H;
-    auto next_unit = [&]() -> int {
-        int v = 0;
-        if (lane0 == 0) v = atomicAdd(p.work_ctr, 1);
-        return __builtin_amdgcn_readfirstlane(v);
-    };
-    int unit;
-    if (p.work_ctr) {
-        unit = next_unit();
-    } else {
-        const int hgroups = (p.H + 3) >> 2;
-        const int h0 = ((int)blockIdx.x % hgroups) * 4 + wave;
-        unit = h0 < p.H ? ((int)blockIdx.x / hgroups) * p.H + h0 : n_units;
-    }
-    for (; unit < n_units; unit = p.work_ctr ? next_unit() : n_units) {
-    // opaque to the optimiser: it would otherwise hoist every lane-dependent address out of the unit loop and keep it in
-    // registers across the unit (124 -> 156 registers: 3 waves per SIMD)
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int a = unit / p.H, h = unit - a * p.H;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hgroups = (p.H + 3) >> 2;
+    const int a = (int)blockIdx.x / hgroups, h = ((int)blockIdx.x % hgroups) * 4 + wave;
+    if (h >= p.H) return;  // the kernel has no workgroup barrier: every wave works on its own LDS slice
     unsigned char* my = lds[wave];
     unsigned char* vimg = my;
     unsigned char* stage = my + SM_VIMG;
@@ -384,7 +357,6 @@ __global__ __launch_bounds__(256, 4) void attn_self_mfma_kernel(const SelfMfmaPa
             *reinterpret_cast<half4*>(p.out + pa_off(row, h * 64 + dt * 16 + 4 * qg, D >> 5)) =
                 half4{(_Float16)(o[dt][0] * inv), (_Float16)(o[dt][1] * inv), (_Float16)(o[dt][2] * inv), (_Float16)(o[dt][3] * inv)};
     }
-    }  // units
 }
 
 // Non-temporal K / V loads (they bypass the CU's L1: every row is used once, by one wave): 65.2 -> 50.6 us on the kernel
@@ -399,51 +371,26 @@ static bool self_mfma_nt() {
     return nt;
 }
 
-// grid of the work-stealing form: the waves the device holds at once (4 workgroups of 4 waves per CU)
-static unsigned self_mfma_resident_wgs() {
-    static int cus[64];
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return 1024;
-    if (!cus[dev]) HIP_CHECK(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
-    return 4u * (unsigned)cus[dev];
-}
-// WRS_SELF_STEAL=0 (test build, read once per process): one wave per unit, as before round 3
-static bool self_mfma_steal() {
-    static const bool on = !(exp_env("WRS_SELF_STEAL") && exp_env("WRS_SELF_STEAL")[0] == '0');
-    return on;
-}
-static void launch_self_mfma(SelfMfmaParams& p, int n_rows, int G, int H, int* kcount, int work_slot, hipStream_t s) {
-    p.n_audio = n_rows / G;
-    const unsigned per_unit_grid = (unsigned)(p.n_audio * ((H + 3) / 4));
-    unsigned grid = per_unit_grid;
-    p.work_ctr = nullptr;
-    if (work_slot >= 0 && self_mfma_steal()) {
-        WRS_REQUIRE(work_slot < SELF_WORK_CTRS, "attn_self_mfma: work counter %d out of range", work_slot);
-        p.work_ctr = kcount + p.n_audio + work_slot;
-        grid = std::min(self_mfma_resident_wgs(), (unsigned)cdiv((int64_t)p.n_audio * H, 4));
-    }
-    if (self_mfma_nt()) attn_self_mfma_kernel<true><<<grid, 256, 0, s>>>(p);
-    else attn_self_mfma_kernel<false><<<grid, 256, 0, s>>>(p);
-}
-
 void launch_attn_self_mfma_q16(const half_t* q16, half_t* kc, half_t* vc, int n_ctx, int n_rows, int G, int H, int D, const StepParams* sp,
-                               const int* klist, int klist_stride, int* kcount, int work_slot, half_t* out, hipStream_t s) {
+                               const int* klist, int klist_stride, const int* kcount, half_t* out, hipStream_t s) {
     WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && q16, "attn_self_mfma: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
     WRS_REQUIRE(G >= 1 && G <= 8 && n_rows % G == 0 && klist && kcount, "attn_self_mfma: bad group size %d for %d rows", G, n_rows);
     WRS_REQUIRE((int64_t)n_rows * n_ctx * D * 2 < (1ll << 32), "attn_self_mfma: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
-    SelfMfmaParams p{nullptr, 1, 0, nullptr, 1.f, kc, vc, n_ctx, G, H, D, sp, klist, klist_stride, kcount, out, 0, nullptr, q16};
-    launch_self_mfma(p, n_rows, G, H, kcount, work_slot, s);
+    SelfMfmaParams p{nullptr, 1, 0, nullptr, 1.f, kc, vc, n_ctx, G, H, D, sp, klist, klist_stride, kcount, out, q16};
+    if (self_mfma_nt()) attn_self_mfma_kernel<true><<<(n_rows / G) * ((H + 3) / 4), 256, 0, s>>>(p);
+    else attn_self_mfma_kernel<false><<<(n_rows / G) * ((H + 3) / 4), 256, 0, s>>>(p);
 }
 
 void launch_attn_self_mfma(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc, int n_ctx,
-                           int n_rows, int G, int H, int D, const StepParams* sp, const int* klist, int klist_stride, int* kcount, int work_slot,
+                           int n_rows, int G, int H, int D, const StepParams* sp, const int* klist, int klist_stride, const int* kcount,
                            half_t* out, hipStream_t s) {
     WRS_REQUIRE(n_ctx <= 512 && D == H * 64 && qkv_slab && qkv_bias && ksplit >= 1, "attn_self_mfma: bad shape n_ctx=%d D=%d H=%d", n_ctx, D, H);
     WRS_REQUIRE(G >= 1 && G <= 8 && n_rows % G == 0 && klist && kcount, "attn_self_mfma: bad group size %d for %d rows", G, n_rows);
     WRS_REQUIRE((int64_t)n_rows * n_ctx * D * 2 < (1ll << 32), "attn_self_mfma: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
-    SelfMfmaParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, n_ctx, G, H, D, sp, klist, klist_stride, kcount, out, 0, nullptr, nullptr};
-    launch_self_mfma(p, n_rows, G, H, kcount, work_slot, s);
+    SelfMfmaParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, n_ctx, G, H, D, sp, klist, klist_stride, kcount, out, nullptr};
+    const int n_audio = n_rows / G;
+    if (self_mfma_nt()) attn_self_mfma_kernel<true><<<n_audio * ((H + 3) / 4), 256, 0, s>>>(p);
+    else attn_self_mfma_kernel<false><<<n_audio * ((H + 3) / 4), 256, 0, s>>>(p);
 }
 
 }  // namespace wrs

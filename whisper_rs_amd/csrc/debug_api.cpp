@@ -132,7 +132,7 @@ int wrs_debug_attn_self_run(wrs_debug_attn_self* a) {
             const bool direct = a->q16_mode == 3;  // q as fp16, new k / v already in the cache and in the key list
             DevBuf klist, kcount, qd;
             klist.alloc((size_t)n_audio * stride * 4);
-            kcount.alloc((size_t)(n_audio + SELF_WORK_CTRS) * 4);  // counts + the work counters launch_self_keys zeroes
+            kcount.alloc((size_t)n_audio * 4);
             launch_self_keys(anc.as<int>(), (int64_t)R * a->n_ctx, a->n_ctx, n_audio, a->rows_per_audio, sp.as<StepParams>(), klist.as<int>(), stride,
                              kcount.as<int>(), direct, s);
             if (direct) {  // what the QKV GEMM's epilogue leaves: prepared on the host from the same qkv / bias / scale
@@ -154,10 +154,10 @@ int wrs_debug_attn_self_run(wrs_debug_attn_self* a) {
                 }
                 HIP_CHECK(hipMemcpy(qd.p, q16.data(), q16.size() * 2, hipMemcpyHostToDevice));
                 launch_attn_self_mfma_q16(qd.as<half_t>(), reinterpret_cast<half_t*>(a->kc), reinterpret_cast<half_t*>(a->vc), a->n_ctx, R, a->rows_per_audio,
-                                          a->H, a->D, sp.as<StepParams>(), klist.as<int>(), stride, kcount.as<int>(), 0, reinterpret_cast<half_t*>(a->out_packed), s);
+                                          a->H, a->D, sp.as<StepParams>(), klist.as<int>(), stride, kcount.as<int>(), reinterpret_cast<half_t*>(a->out_packed), s);
             } else {
                 launch_attn_self_mfma(a->qkv, 1, R, a->qkv_bias, a->scale, reinterpret_cast<half_t*>(a->kc), reinterpret_cast<half_t*>(a->vc), a->n_ctx, R,
-                                      a->rows_per_audio, a->H, a->D, sp.as<StepParams>(), klist.as<int>(), stride, kcount.as<int>(), 0,
+                                      a->rows_per_audio, a->H, a->D, sp.as<StepParams>(), klist.as<int>(), stride, kcount.as<int>(),
                                       reinterpret_cast<half_t*>(a->out_packed), s);
             }
             HIP_CHECK(hipStreamSynchronize(s));

@@ -262,16 +262,12 @@ void launch_attn_cross_q16(const half_t* q16, const half_t* kp, const half_t* vp
 // the ancestry table only): klist [n_audio][klist_stride >= G * n_ctx], kcount [n_audio]; phys_mul must be 1.
 // include_new: the list also holds the step's own position (one key per beam, owned by that beam): for the form of the
 // attention kernel that finds q as fp16 and the new k / v already in the cache (launch_attn_self_mfma_q16)
-// kcount holds n_audio counts FOLLOWED BY SELF_WORK_CTRS work counters, which launch_self_keys zeroes: attention launch number
-// `work_slot` of the step (the layer index; every launch of a step needs its own) hands its (audio, head) units out through
-// counter work_slot to a grid of resident waves; work_slot < 0: one wave per unit.
-static constexpr int SELF_WORK_CTRS = 64;
 void launch_self_keys(const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_audio, int G, const StepParams* sp, int* klist,
                       int klist_stride, int* kcount, bool include_new, hipStream_t s);
 void launch_attn_self_mfma_q16(const half_t* q16, half_t* kc, half_t* vc, int n_ctx, int n_rows, int G, int H, int D, const StepParams* sp,
-                               const int* klist, int klist_stride, int* kcount, int work_slot, half_t* out, hipStream_t s);
+                               const int* klist, int klist_stride, const int* kcount, half_t* out, hipStream_t s);
 void launch_attn_self_mfma(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc, int n_ctx,
-                           int n_rows, int G, int H, int D, const StepParams* sp, const int* klist, int klist_stride, int* kcount, int work_slot,
+                           int n_rows, int G, int H, int D, const StepParams* sp, const int* klist, int klist_stride, const int* kcount,
                            half_t* out, hipStream_t s);
 void launch_anc_init(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_phys_rows, int G, hipStream_t s);
 void launch_anc_update(int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, const StepParams* sp,

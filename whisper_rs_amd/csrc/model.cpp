@@ -533,7 +533,7 @@ void Model::resize_ctx(DecState& st, int ctx) {
     st.vc.alloc((size_t)L_dec * st.r_cap * ctx * D * 2);
     st.anc.alloc((size_t)2 * st.r_cap * ctx * 4);
     st.self_keys_stride = (st.r_cap / std::max(st.a_cap, 1)) * ctx + 1;  // [0] = count
-    st.self_keys.alloc(((size_t)st.a_cap * st.self_keys_stride + st.a_cap + SELF_WORK_CTRS) * 4);  // lists, counts, work counters
+    st.self_keys.alloc(((size_t)st.a_cap * st.self_keys_stride + st.a_cap) * 4);
     if (st.f32) {  // f32 parity mode: its fp32 caches follow
         st.f32->kc.alloc((size_t)L_dec * st.r_cap * ctx * D * 4);
         st.f32->vc.alloc((size_t)L_dec * st.r_cap * ctx * D * 4);
@@ -647,10 +647,10 @@ void Model::decoder_step(DecState& st, int rows, int phys_mul, int q_per_audio, 
             Timed tm(timer, "dec_attn_self", stream);
             if (qkv_direct)
                 launch_attn_self_mfma_q16(st.q16.as<half_t>(), st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer, st.ctx, rows,
-                                          q_per_audio, H, D, sp, self_klist, st.self_keys_stride, self_kcount, l, st.att.as<half_t>(), stream);
+                                          q_per_audio, H, D, sp, self_klist, st.self_keys_stride, self_kcount, st.att.as<half_t>(), stream);
             else if (self_mfma)
                 launch_attn_self_mfma(slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer, st.ctx,
-                                      rows, q_per_audio, H, D, sp, self_klist, st.self_keys_stride, self_kcount, l, st.att.as<half_t>(), stream);
+                                      rows, q_per_audio, H, D, sp, self_klist, st.self_keys_stride, self_kcount, st.att.as<half_t>(), stream);
             else
                 launch_attn_self(slab, ks_qkv, mp, b.qkv_b, scale, st.kc.as<half_t>() + l * kv_layer, st.vc.as<half_t>() + l * kv_layer,
                                  st.anc.as<int>(), anc_stride, st.ctx, rows, q_per_audio, phys_mul, H, D, sp, st.att.as<half_t>(), stream);
