@@ -67,7 +67,8 @@ typedef struct wrs_debug_gemm {
     int32_t ksplit;          /* tiled path: > 1 = split-K, raw fp32 partial sums [ksplit][slab_stride]; path DEC: out = slabs used */
     int64_t slab_stride;     /* tiled path in; path DEC: out = m_pad * N */
     /* path PRING: epilogue mode, tile rows (64 / 128); RESID updates `c` (fp32 [M, ldc]) in place; QKV writes q to `c`
-     * (fp16 [M, ldc], ldc >= N/3) and k / v to kcache / vcache (fp16 [M * phys_mul][n_ctx][N/3]) at position cache_pos */
+     * (fp16 [M, ldc], ldc >= N/3) and k / v to kcache / vcache (fp16 [M * phys_mul][n_ctx][N/3]) at position cache_pos.
+     * Path TILED with kcache != NULL: the tiled kernel's QKV-to-cache epilogue (same outputs, phys_mul 1, c fp16 with ldc = N/3) */
     int32_t pring_mode, pring_bm;
     void* kcache;
     void* vcache;

@@ -215,15 +215,18 @@ DEC_SHAPES = [("qkv", 3 * D, D), ("attn_out", D, D), ("mlp2", D, 4 * D)]
 
 @pytest.mark.parametrize("force", [DBG.GEMM_AUTO, DBG.GEMM_TILE128_PACKED, DBG.GEMM_RING], ids=["auto", "tile128p", "ring"])
 @pytest.mark.parametrize("name,N,K", DEC_SHAPES, ids=[s[0] for s in DEC_SHAPES])
-@pytest.mark.parametrize("M", [1280, 500])
+@pytest.mark.parametrize("M", [1280, 500, 1535])
 def test_decode_step_slab_gemms(gpu, M, name, N, K, force):
     """packed activations, fp32 slabs, the split-K the decode step uses (2 for the N = D shapes at 1280 rows: the
-    LDS-transposed slab store) and split 1; 1280 rows = 256 windows x beam 5, 500 rows = edge row tile."""
+    LDS-transposed slab store) and split 1; 1280 rows = 256 windows x beam 5, 500 rows = edge row tile, 1535 rows = the
+    bench's 307 windows x beam 5 with the slab padded to the consumer's row stride (1600 rows, as Model::decoder_step
+    allocates it): the last row tile then also goes through the LDS-transposed store and writes its 128th row into the padding."""
     a = _rand((M, K), 21)
     w = _rand((N, K), 22, K ** -0.5).float()
     ref = a.float() @ w.t()
     for ksplit in sorted({1, _dec_split(M, N, K), 2}):
-        got, used = _tiled(a, w, M, N, K, force=force, packed=True, ksplit=ksplit)
+        got, used = _tiled(a, w, M, N, K, force=force, packed=True, ksplit=ksplit, c_rows=1600 if M == 1535 else None)
+        got = got[..., :M, :]
         if ksplit > 1:
             got = got.sum(0)
         err = _rel_err(got, ref)
@@ -236,7 +239,7 @@ def test_decode_step_slab_gemms(gpu, M, name, N, K, force):
 
 
 @pytest.mark.parametrize("force", [DBG.GEMM_AUTO, DBG.GEMM_RING], ids=["auto", "ring"])
-@pytest.mark.parametrize("M", [1280, 500])
+@pytest.mark.parametrize("M", [1280, 500, 1535])
 def test_decode_step_mlp1_packed_gelu(gpu, M, force):
     """MLP-1 of the decode step at >= 480 rows: bias + exact GELU + fp16 store in packed-activation order."""
     N, K = 4 * D, D
@@ -396,3 +399,43 @@ def test_pring_qkv_epilogue_writes_cache(gpu, M, cache_pos):
     kc0[:, cache_pos], vc0[:, cache_pos] = kc[:, cache_pos], vc[:, cache_pos]
     assert torch.equal(kc, kc0) and torch.equal(vc, vc0)
     print(f"pring QKV M={M} cache_pos={cache_pos} workgroups={wgs}: q/k/v ok")
+
+
+@pytest.mark.parametrize("M,cache_pos", [(1535, 17), (1280, 0), (500, 447)])
+def test_tiled_qkv_epilogue_writes_cache(gpu, M, cache_pos):
+    """The form the benchmark runs at >= 480 rows: the QKV projection on the 128x128 packed-A kernel, its epilogue writing q
+    (bias, scale) as fp16 [M, D] and the new k (scale) / v (bias) rows into the K/V cache at the step's position, with 16-byte
+    stores of 8 consecutive columns (two column groups exchanged between lane rows).  1535 rows = 307 windows x beam 5: the last
+    row tile is partial; nothing else in the cache may change."""
+    n_ctx = 448
+    a = _rand((M, D), 191)
+    w = _rand((3 * D, D), 192, D ** -0.5).float()
+    bias = _rand((3 * D,), 193, 0.1).float()
+    bias[D:2 * D] = 0.0  # the key projection has no bias (model.rs:138-141)
+    scale = 64 ** -0.25
+    kc = _rand((M, n_ctx, D), 194, 1.0).to(torch.float16)
+    vc = _rand((M, n_ctx, D), 195, 1.0).to(torch.float16)
+    kc0, vc0 = kc.clone(), vc.clone()
+    dev = _dev()
+    g = DBG.DebugGemmC()
+    g.device_id, g.path, g.force_kernel = 0, DBG.PATH_TILED, DBG.GEMM_AUTO
+    g.M, g.N, g.K = M, 3 * D, D
+    rows_pad = -(-M // 128) * 128
+    ap = DBG.pack_activations(a, rows_pad)
+    g.a, g.a_packed, g.packed_rows = ap.data_ptr(), 1, rows_pad
+    g.w, g.n_w, g.k_w = w.data_ptr(), 3 * D, D
+    g.bias, g.scale, g.scale_n_end = bias.data_ptr(), scale, 2 * D
+    q = torch.zeros(M, D, dtype=torch.float16, device=dev)
+    g.c, g.c_f32, g.c_packed, g.ldc, g.ksplit = q.data_ptr(), 0, 0, D, 1
+    g.kcache, g.vcache, g.n_ctx, g.cache_pos, g.phys_mul = kc.data_ptr(), vc.data_ptr(), n_ctx, cache_pos, 1
+    used = _run(g)
+    # 4 x 30 tiles at 500 rows give a CU at most one workgroup: the launcher takes the ring kernel (same epilogue code)
+    assert used == (DBG.GEMM_RING if M == 500 else DBG.GEMM_TILE128_PACKED)
+    ref = a.float() @ w.t() + bias
+    ref[:, :2 * D] *= scale
+    assert _rel_err(q.float(), ref[:, :D]) < TOL_F16
+    assert _rel_err(kc[:, cache_pos].float(), ref[:, D:2 * D]) < TOL_F16
+    assert _rel_err(vc[:, cache_pos].float(), ref[:, 2 * D:]) < TOL_F16
+    keep = torch.ones(n_ctx, dtype=torch.bool, device=dev)
+    keep[cache_pos] = False
+    assert torch.equal(kc[:, keep], kc0[:, keep]) and torch.equal(vc[:, keep], vc0[:, keep]), "a cache position other than the step's was written"

@@ -139,8 +139,9 @@ __device__ __forceinline__ half8 kv_load(const half_t* ptr) {
 
 // NQ (encoder only): query tiles of 16 per wave; every K/V fragment fetched is used NQ times from registers.  The kernel
 // turned out to be bound by the softmax VALU work per (query tile, key block), not by the loads: NQ = 2 gains 4 %.
-template <bool SPLIT, int NQ>
-__global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(const AttnParams p) {
+// XW (SPLIT only): waves per workgroup
+template <bool SPLIT, int NQ, int XW = XA_WAVES>
+__global__ __launch_bounds__(SPLIT ? XW * 64 : 256) void attn_mfma_kernel(const AttnParams p) {
     static_assert(!SPLIT || NQ == 1, "the decode kernel has one query tile (the beams of an audio)");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int h, b, qblk = 0;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
     const half_t* vbase = p.vp + head_base + lane * 8;
     int n_blocks = p.Tp / 32;
     if (!SPLIT && p.causal) n_blocks = min(n_blocks, (q0 + 16 * NQ - 1) / 32 + 1);  // key blocks past the wave's last query are fully masked
-    const int kb_begin = SPLIT ? wave : 0, kb_step = SPLIT ? XA_WAVES : 1;
+    const int kb_begin = SPLIT ? wave : 0, kb_step = SPLIT ? XW : 1;
 
     floatx4 o[NQ][4];
     float m_run[NQ], l_run[NQ];
@@ -307,9 +308,9 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
         }
         return;
     } else {
-        __shared__ float sm[XA_WAVES][16];
-        __shared__ float sl[XA_WAVES][16];
-        __shared__ float so[XA_WAVES][64][17];
+        __shared__ float sm[XW][16];
+        __shared__ float sl[XW][16];
+        __shared__ float so[XW][64][17];
         if (qg == 0) {
             sm[wave][qcol] = m_run[0];
             sl[wave][qcol] = l_run[0];
@@ -324,10 +325,10 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
         if (tid < 256 && qq < n_valid) {
             float mm = sm[0][qq];
 #pragma unroll
-            for (int w = 1; w < XA_WAVES; ++w) mm = fmaxf(mm, sm[w][qq]);
-            float wgt[XA_WAVES], lsum = 0.f;
+            for (int w = 1; w < XW; ++w) mm = fmaxf(mm, sm[w][qq]);
+            float wgt[XW], lsum = 0.f;
 #pragma unroll
-            for (int w = 0; w < XA_WAVES; ++w) {
+            for (int w = 0; w < XW; ++w) {
                 wgt[w] = __expf(sm[w][qq] - mm);  // waves that saw no key block hold m = -inf, l = 0 -> weight 0
                 lsum += wgt[w] * sl[w][qq];
             }
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(SPLIT ? XA_WAVES * 64 : 256) void attn_mfma_kernel(
             for (int r = 0; r < 4; ++r) {
                 float a = 0.f;
 #pragma unroll
-                for (int w = 0; w < XA_WAVES; ++w) a += wgt[w] * so[w][d0 + r][qq];
+                for (int w = 0; w < XW; ++w) a += wgt[w] * so[w][d0 + r][qq];
                 r4[r] = a * inv;
             }
             // decode output feeds the out-projection GEMM: packed activation order (K = H*64)
@@ -498,6 +499,7 @@ void launch_attn_cross(const float* q_slab, int q_ksplit, int q_m_pad, const flo
     WRS_REQUIRE(T >= 1 && q_slab && q_bias && q_ksplit >= 1, "attn_cross: bad argument");
     AttnParams p{nullptr, 0, kp, vp, T, (int)round_up(T, 32), H, G, G, out, 0, q_slab, q_ksplit, q_m_pad, q_bias, q_scale, 0, 0};
     dim3 grid(1, (unsigned)H, (unsigned)n_audio);
+    // (16 waves per workgroup when the launch has only a window's 20 workgroups: 14.4 us against 12.9 us, round 3: not used)
     attn_mfma_kernel<true, 1><<<grid, XA_WAVES * 64, 0, s>>>(p);
 }
 
@@ -545,18 +547,29 @@ __device__ __forceinline__ void slab_chunk8(const float* __restrict__ slab, int 
     }
 }
 
+// PSPLIT = false: one workgroup = (up to) 4 heads of ONE row, a wave per head.  PSPLIT = true (a window or two: a few dozen rows):
+// one workgroup = ONE (row, head), its 4 waves take every 4th block of 32 cached positions and are merged through LDS — a wave's
+// walk is a chain of dependent memory round trips (one per 32 positions), 4 waves cut it to a quarter.
+template <bool PSPLIT>
 __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) {
-    // one workgroup = (up to) 4 heads of ONE row, so the row's ancestry entries are fetched once
     __shared__ int anc_s[512];
+    __shared__ float ps_m[4], ps_l[4], ps_o[4][64];  // PSPLIT: the waves' partial (max, denominator, output)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hpb = (p.H + 3) >> 2;                 // head groups per row
-    // XCD-aware order: the G beams of one (audio, head group) run back-to-back on ONE XCD, so the K/V rows they
-    // share through the ancestry table (common beam prefixes) are fetched into that L2 once.  Speed only.
-    const int G = p.rows_per_audio;
-    const int j = (int)(blockIdx.x >> 3);
-    const int unit = (j / G) * 8 + (int)(blockIdx.x & 7);  // (audio, head group)
-    if (unit >= (p.n_rows / G) * hpb) return;               // whole workgroup, before any barrier
-    const int row = (unit / hpb) * G + j % G, h = (unit % hpb) * 4 + wave;
+    int row, h;
+    if (PSPLIT) {
+        row = (int)blockIdx.x / p.H;
+        h = (int)blockIdx.x % p.H;
+    } else {
+        // XCD-aware order: the G beams of one (audio, head group) run back-to-back on ONE XCD, so the K/V rows they
+        // share through the ancestry table (common beam prefixes) are fetched into that L2 once.  Speed only.
+        const int G = p.rows_per_audio;
+        const int j = (int)(blockIdx.x >> 3);
+        const int unit = (j / G) * 8 + (int)(blockIdx.x & 7);  // (audio, head group)
+        if (unit >= (p.n_rows / G) * hpb) return;               // whole workgroup, before any barrier
+        row = (unit / hpb) * G + j % G;
+        h = (unit % hpb) * 4 + wave;
+    }
     const int g = lane >> 3, c = lane & 7;
     const int D = p.D;
     const int cpos = p.sp->cache_pos;  // the new token's slot; cached positions are 0..cpos-1
@@ -596,7 +609,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
             kn[j] = (float)k16[j];  // use exactly what later steps will read back from the fp16 cache
             vn[j] = (float)v16[j];
         }
-        if (g == 0) {
+        if (g == 0 && (!PSPLIT || wave == 0)) {
             *reinterpret_cast<half8*>(p.kc + (int64_t)phys * row_stride + (int64_t)cpos * D + col) = k16;
             *reinterpret_cast<half8*>(p.vc + (int64_t)phys * row_stride + (int64_t)cpos * D + col) = v16;
         }
@@ -614,14 +627,17 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
         s_new += (float)qh[j][0] * kn[2 * j] + (float)qh[j][1] * kn[2 * j + 1];
     }
     s_new = sum8(s_new);
-    float m_run = s_new;  // the new position seeds the running max (weight exp(0) = 1), counted once by group 0
-    float l_run = (g == 0) ? 1.f : 0.f;
+    const bool seed = !PSPLIT || wave == 0;  // the new position is counted once: by group 0 (of wave 0)
+    // the new position seeds the running max (weight exp(0) = 1); a wave without it starts from a finite floor so that
+    // exp(m_run - m_new) is exp(-huge) = 0, never exp(-inf + inf)
+    float m_run = seed ? s_new : -1.0e30f;
+    float l_run = (seed && g == 0) ? 1.f : 0.f;
     float acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = (g == 0) ? vn[j] : 0.f;
+    for (int j = 0; j < 8; ++j) acc[j] = (seed && g == 0) ? vn[j] : 0.f;
 
     const unsigned row_stride_b = (unsigned)(p.n_ctx * D * 2);
-    for (int p0 = 0; p0 < cpos; p0 += 32) {
+    for (int p0 = PSPLIT ? wave * 32 : 0; p0 < cpos; p0 += PSPLIT ? 128 : 32) {
         half8 kv[4], vv[4];
         bool ok[4];
 #pragma unroll
@@ -685,6 +701,26 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o);
     }
+    if (PSPLIT) {  // the 4 waves' partial results -> wave 0
+        if (g == 0) {
+            if (c == 0) { ps_m[wave] = m_run; ps_l[wave] = l_run; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ps_o[wave][c * 8 + j] = acc[j];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        const float mm = fmaxf(fmaxf(ps_m[0], ps_m[1]), fmaxf(ps_m[2], ps_m[3]));  // wave 0 holds the new position: finite
+        l_run = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float wgt = __expf(ps_m[w] - mm);
+            l_run += wgt * ps_l[w];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += wgt * ps_o[w][c * 8 + j];
+        }
+    }
     if (g == 0) {
         const float inv = 1.f / l_run;
         half8 r;
@@ -694,6 +730,9 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
     }
 }
 
+// rows at or below this count take the position-split form (one workgroup per (row, head))
+static constexpr int SELF_PSPLIT_MAX_ROWS = 40;
+
 void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc,
                       const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, int rows_per_audio, int phys_mul, int H, int D,
                       const StepParams* sp, half_t* out, hipStream_t s) {
@@ -701,9 +740,13 @@ void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float*
     WRS_REQUIRE((int64_t)n_rows * phys_mul * n_ctx * D * 2 < (1ll << 32), "attn_self: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
     WRS_REQUIRE(rows_per_audio >= 1 && n_rows % rows_per_audio == 0, "attn_self: rows %d not a multiple of %d", n_rows, rows_per_audio);
     SelfAttnParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio, nullptr};
+    if (n_rows <= SELF_PSPLIT_MAX_ROWS) {
+        attn_self_kernel<true><<<(unsigned)(n_rows * H), 256, 0, s>>>(p);
+        return;
+    }
     const int64_t units = (int64_t)(n_rows / rows_per_audio) * ((H + 3) / 4);
     const unsigned grid = (unsigned)(8 * cdiv(units, 8) * rows_per_audio);
-    attn_self_kernel<<<grid, 256, 0, s>>>(p);
+    attn_self_kernel<false><<<grid, 256, 0, s>>>(p);
 }
 
 void launch_attn_self_q16(const half_t* q16, half_t* kc, half_t* vc, const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows,
@@ -712,9 +755,13 @@ void launch_attn_self_q16(const half_t* q16, half_t* kc, half_t* vc, const int* 
     WRS_REQUIRE((int64_t)n_rows * phys_mul * n_ctx * D * 2 < (1ll << 32), "attn_self: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
     WRS_REQUIRE(rows_per_audio >= 1 && n_rows % rows_per_audio == 0, "attn_self: rows %d not a multiple of %d", n_rows, rows_per_audio);
     SelfAttnParams p{nullptr, 1, 0, nullptr, 1.f, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio, q16};
+    if (n_rows <= SELF_PSPLIT_MAX_ROWS) {
+        attn_self_kernel<true><<<(unsigned)(n_rows * H), 256, 0, s>>>(p);
+        return;
+    }
     const int64_t units = (int64_t)(n_rows / rows_per_audio) * ((H + 3) / 4);
     const unsigned grid = (unsigned)(8 * cdiv(units, 8) * rows_per_audio);
-    attn_self_kernel<<<grid, 256, 0, s>>>(p);
+    attn_self_kernel<false><<<grid, 256, 0, s>>>(p);
 }
 
 void launch_attn_cross_q16(const half_t* q16, const half_t* kp, const half_t* vp, int n_audio, int G, int T, int H, half_t* out, hipStream_t s) {
@@ -722,6 +769,7 @@ void launch_attn_cross_q16(const half_t* q16, const half_t* kp, const half_t* vp
     WRS_REQUIRE(T >= 1 && q16, "attn_cross: bad argument");
     AttnParams p{q16, (int64_t)H * 64, kp, vp, T, (int)round_up(T, 32), H, G, G, out, 0, nullptr, 0, 0, nullptr, 1.f, 0, 0};
     dim3 grid(1, (unsigned)H, (unsigned)n_audio);
+    // (16 waves per workgroup when the launch has only a window's 20 workgroups: 14.4 us against 12.9 us, round 3: not used)
     attn_mfma_kernel<true, 1><<<grid, XA_WAVES * 64, 0, s>>>(p);
 }
 

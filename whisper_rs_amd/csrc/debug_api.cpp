@@ -62,6 +62,18 @@ int wrs_debug_gemm_f16(wrs_debug_gemm* g) {
             e.c_packed = g->c_packed;
             e.ksplit = g->ksplit > 1 ? g->ksplit : 1;
             e.slab_stride = g->slab_stride;
+            DevBuf sp;
+            if (g->kcache) {  // the decode step's QKV-to-cache epilogue of the tiled kernel (what the benchmark runs at >= 480 rows)
+                WRS_REQUIRE(g->vcache && g->n_ctx > 0 && g->cache_pos >= 0 && g->cache_pos < g->n_ctx && g->N % 3 == 0, "wrs_debug_gemm_f16: bad QKV cache arguments");
+                sp.alloc(sizeof(StepParams));
+                StepParams h{};
+                h.cache_pos = g->cache_pos; h.n_rows = (int)g->M;
+                HIP_CHECK(hipMemcpyAsync(sp.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                e.qkv_d_model = (int)(g->N / 3);
+                e.kcache = reinterpret_cast<half_t*>(g->kcache); e.vcache = reinterpret_cast<half_t*>(g->vcache);
+                e.cache_row_stride = (int64_t)g->n_ctx * (g->N / 3); e.sp = sp.as<StepParams>();
+            }
             gemm_debug_force(g->force_kernel);
             try {
                 launch_gemm_f16(A, wp.as<half_t>(), g->M, g->N, g->K, e, s);
