@@ -730,8 +730,12 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const SelfAttnParams p) 
     }
 }
 
-// rows at or below this count take the position-split form (one workgroup per (row, head))
+// rows at or below this count take the position-split form (one workgroup per (row, head)); WRS_SELF_PSPLIT_ROWS (test build) overrides
 static constexpr int SELF_PSPLIT_MAX_ROWS = 40;
+static int self_psplit_max_rows() {
+    static const int v = exp_env("WRS_SELF_PSPLIT_ROWS") ? atoi(exp_env("WRS_SELF_PSPLIT_ROWS")) : SELF_PSPLIT_MAX_ROWS;
+    return v;
+}
 
 void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float* qkv_bias, float scale, half_t* kc, half_t* vc,
                       const int* anc_base, int64_t anc_buf_stride, int n_ctx, int n_rows, int rows_per_audio, int phys_mul, int H, int D,
@@ -740,7 +744,7 @@ void launch_attn_self(const float* qkv_slab, int ksplit, int m_pad, const float*
     WRS_REQUIRE((int64_t)n_rows * phys_mul * n_ctx * D * 2 < (1ll << 32), "attn_self: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
     WRS_REQUIRE(rows_per_audio >= 1 && n_rows % rows_per_audio == 0, "attn_self: rows %d not a multiple of %d", n_rows, rows_per_audio);
     SelfAttnParams p{qkv_slab, ksplit, m_pad, qkv_bias, scale, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio, nullptr};
-    if (n_rows <= SELF_PSPLIT_MAX_ROWS) {
+    if (n_rows <= self_psplit_max_rows()) {
         attn_self_kernel<true><<<(unsigned)(n_rows * H), 256, 0, s>>>(p);
         return;
     }
@@ -755,7 +759,7 @@ void launch_attn_self_q16(const half_t* q16, half_t* kc, half_t* vc, const int* 
     WRS_REQUIRE((int64_t)n_rows * phys_mul * n_ctx * D * 2 < (1ll << 32), "attn_self: a layer's K/V cache must stay below 4 GiB (32-bit offsets)");
     WRS_REQUIRE(rows_per_audio >= 1 && n_rows % rows_per_audio == 0, "attn_self: rows %d not a multiple of %d", n_rows, rows_per_audio);
     SelfAttnParams p{nullptr, 1, 0, nullptr, 1.f, kc, vc, anc_base, anc_buf_stride, n_ctx, n_rows, phys_mul, H, D, sp, out, rows_per_audio, q16};
-    if (n_rows <= SELF_PSPLIT_MAX_ROWS) {
+    if (n_rows <= self_psplit_max_rows()) {
         attn_self_kernel<true><<<(unsigned)(n_rows * H), 256, 0, s>>>(p);
         return;
     }
