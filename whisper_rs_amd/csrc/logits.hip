@@ -29,6 +29,37 @@ __device__ __forceinline__ float wave_add(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// 64-lane maximum on the VALU (DPP inside the 16-lane rows, v_permlane swaps between them): the K-th-largest bound below is
+// refreshed inside the pass, where six ds_bpermute round trips per maximum would cost what it saves
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false)));
+}
+__device__ __forceinline__ float wave_max_valu(float v) {
+    v = dpp_max<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_max<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_max<0x141>(v);  // row_half_mirror
+    v = dpp_max<0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row's maximum
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+// K-th largest of the 64 lanes' values (wave-uniform; -inf when fewer than K lanes hold a finite value).  With x = every lane's
+// best candidate so far this is a LOWER bound of the wave's K-th best candidate: a value below it cannot be among the K best of
+// the row, whatever comes later.
+__device__ __forceinline__ float wave_kth_largest(float x, int K) {
+    int need = K;
+#pragma unroll 1
+    for (int r = 0; r < TOPK_MAX; ++r) {
+        const float m = wave_max_valu(x);
+        if (m == -INFINITY) break;
+        need -= __popcll(__ballot(x == m));
+        if (need <= 0) return m;
+        if (x == m) x = -INFINITY;
+    }
+    return -INFINITY;
+}
 __device__ __forceinline__ float block_max(float v, float* sh) {
     v = wave_max(v);
     __syncthreads();
@@ -178,7 +209,13 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
     }
     typedef float floatx4 __attribute__((ext_vector_type(4)));
     const bool vec_ok = (p.ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.logits) & 15) == 0);
-    for (int v0 = v_begin + tid * 4; v0 < v_end; v0 += 1024) {
+    // tau_t: wave-uniform lower bound of the K-th best allowed text value (refreshed after iterations 1, 3, 7, 15, 31 from the
+    // lanes' best candidates): text values below it skip the top-8 insertion.  Without it the insertion — an 8-step shift that
+    // the whole wave executes whenever ANY lane's value beats that lane's own 8th best — ran ~200 times per wave and made a
+    // full row's pass 4x its memory time (round 3: 77 us for rows that allow nearly nothing, 305 us for full rows).
+    float tau_t = -INFINITY;
+    int it = 0;
+    for (int v0 = v_begin + tid * 4; v0 < v_end; v0 += 1024, ++it) {
         float val4[4];
         if (vec_ok && v0 + 4 <= p.ld) {
             const floatx4 t = ld_stream(reinterpret_cast<const floatx4*>(x + v0));  // a row's logits are read once
@@ -201,13 +238,17 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
             if (v < tsb) {
                 if (val > mt) { st = st * __expf(mt - val) + 1.f; mt = val; }
                 else st += __expf(val - mt);
-                if (val > tvt[TOPK_MAX - 1] || (val == tvt[TOPK_MAX - 1] && v < tit[TOPK_MAX - 1])) topk_insert(tvt, tit, val, v);
+                if (val >= tau_t && (val > tvt[TOPK_MAX - 1] || (val == tvt[TOPK_MAX - 1] && v < tit[TOPK_MAX - 1]))) topk_insert(tvt, tit, val, v);
             } else {
                 if (val > ms) { ss = ss * __expf(ms - val) + 1.f; ms = val; }
                 else ss += __expf(val - ms);
                 if (val > tvs[TOPK_MAX - 1] || (val == tvs[TOPK_MAX - 1] && v < tis[TOPK_MAX - 1])) topk_insert(tvs, tis, val, v);
             }
         }
+        // `it` is the same in every lane.  A lane's trip count is the wave's or one less, so the only refresh that can run with lanes
+        // missing is the one at the end of the wave's LAST iteration — whose result nobody uses: every bound that is used was
+        // computed by 64 active lanes (the cross-lane exchanges in wave_kth_largest need that)
+        if (it >= 1 && it <= 31 && (it & (it + 1)) == 0) tau_t = wave_kth_largest(tvt[0], p.k);
     }
     // ---- combine the threads' (max, sum) pairs
     if (PARTIAL) {
