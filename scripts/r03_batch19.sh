@@ -1,7 +1,7 @@
 #!/bin/bash
 # filter kernel with the wave-level K-th-best bound: bit-exact filter tests + decode tests, then the kernel's average in a sequential pass
 set -o pipefail
-out=gpurun_out/r03z2
+out=gpurun_out/r03z3
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout -k 10 600 python3 -m pytest tests/test_gpu_filters.py tests/test_gpu_decode.py tests/test_gpu_golden.py tests/test_gpu_configs.py tests/test_gpu_parity_f32.py -x -q > $out/pytest_subset.log 2>&1 || { tail -30 $out/pytest_subset.log; exit 1; }

@@ -225,24 +225,48 @@ __global__ __launch_bounds__(256) void filter_topk_kernel(const FilterParams p) 
             for (int e = 0; e < 4; ++e) val4[e] = v0 + e < v_end ? x[v0 + e] : -INFINITY;
         }
         const unsigned bits = smem[v0 >> 5] >> (v0 & 31);  // 4 consecutive ids never straddle a 32-bit word (v0 % 4 == 0)
+        // The 4 values as one group per range: the running maximum is raised once per group (rarely, after the first few), ONE
+        // exponential per value (per value, both sides of `if (val > m) rescale else add` ran under divergence: two), the top-8
+        // list touched only when the group's maximum reaches the wave's bound and the lane's last entry.  Masked values enter as
+        // -inf: exp(-inf - m) = 0.
+        float raw[4], tx[4], ts[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int v = v0 + e;
-            if (v >= v_end) continue;
-            float val = val4[e];
-            if (want_ns) {  // softmax of the RAW logits (decode/mod.rs:250-255)
-                if (val > mr) { sr = sr * __expf(mr - val) + 1.f; mr = val; }
-                else sr += __expf(val - mr);
+            const bool in = v < v_end;
+            const bool ok = in && v >= lo && v < hi && !((bits >> e) & 1u);
+            raw[e] = in ? val4[e] : -INFINITY;
+            tx[e] = (ok && v < tsb) ? val4[e] : -INFINITY;
+            ts[e] = (ok && v >= tsb) ? val4[e] : -INFINITY;
+        }
+        if (want_ns) {  // softmax of the RAW logits (decode/mod.rs:250-255)
+            const float g = fmaxf(fmaxf(raw[0], raw[1]), fmaxf(raw[2], raw[3]));
+            if (g > mr) { sr *= __expf(mr - g); mr = g; }  // mr = -inf: sr = 0 * exp(-inf) = 0
+            if (mr > -INFINITY) sr += (__expf(raw[0] - mr) + __expf(raw[1] - mr)) + (__expf(raw[2] - mr) + __expf(raw[3] - mr));
+        }
+        if (v0 < tsb) {  // the group holds text ids (all of it, except the one group ts_begin may fall into)
+            const float g = fmaxf(fmaxf(tx[0], tx[1]), fmaxf(tx[2], tx[3]));
+            if (g > -INFINITY) {
+                if (g > mt) { st *= __expf(mt - g); mt = g; }
+                st += (__expf(tx[0] - mt) + __expf(tx[1] - mt)) + (__expf(tx[2] - mt) + __expf(tx[3] - mt));
+                if (g >= tau_t && g >= tvt[TOPK_MAX - 1]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tx[e] >= tau_t && (tx[e] > tvt[TOPK_MAX - 1] || (tx[e] == tvt[TOPK_MAX - 1] && tx[e] > -INFINITY && v0 + e < tit[TOPK_MAX - 1])))
+                            topk_insert(tvt, tit, tx[e], v0 + e);
+                }
             }
-            if (v < lo || v >= hi || ((bits >> e) & 1u)) continue;
-            if (v < tsb) {
-                if (val > mt) { st = st * __expf(mt - val) + 1.f; mt = val; }
-                else st += __expf(val - mt);
-                if (val >= tau_t && (val > tvt[TOPK_MAX - 1] || (val == tvt[TOPK_MAX - 1] && v < tit[TOPK_MAX - 1]))) topk_insert(tvt, tit, val, v);
-            } else {
-                if (val > ms) { ss = ss * __expf(ms - val) + 1.f; ms = val; }
-                else ss += __expf(val - ms);
-                if (val > tvs[TOPK_MAX - 1] || (val == tvs[TOPK_MAX - 1] && v < tis[TOPK_MAX - 1])) topk_insert(tvs, tis, val, v);
+        }
+        if (v0 + 3 >= tsb) {  // ... timestamp ids
+            const float g = fmaxf(fmaxf(ts[0], ts[1]), fmaxf(ts[2], ts[3]));
+            if (g > -INFINITY) {
+                if (g > ms) { ss *= __expf(ms - g); ms = g; }
+                ss += (__expf(ts[0] - ms) + __expf(ts[1] - ms)) + (__expf(ts[2] - ms) + __expf(ts[3] - ms));
+                if (g >= tvs[TOPK_MAX - 1]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (ts[e] > tvs[TOPK_MAX - 1] || (ts[e] == tvs[TOPK_MAX - 1] && ts[e] > -INFINITY && v0 + e < tis[TOPK_MAX - 1])) topk_insert(tvs, tis, ts[e], v0 + e);
+                }
             }
         }
         // `it` is the same in every lane.  A lane's trip count is the wave's or one less, so the only refresh that can run with lanes
