@@ -7,6 +7,7 @@
 using namespace wrs;
 int main(int argc, char** argv) {
     const int A = argc > 1 ? atoi(argv[1]) : 307, trials = argc > 2 ? atoi(argv[2]) : 2, G = 5, L = 32, D = 1280, H = 20, T = 1500;
+    const int order = argc > 3 ? atoi(argv[3]) : 0;  // 0: layers 0..31, 1: 31..0, 2: a fixed shuffle (is the fast part a place or a moment?)
     hipStream_t s; HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     const size_t per_layer = (size_t)A * H * packed_kv_halfs_per_head(T);
     const int R = A * G, m_pad = (R + 15) / 16 * 16;
@@ -20,7 +21,9 @@ int main(int argc, char** argv) {
         HIP_CHECK(hipMemset(kp.p, 0x11, kp.bytes)); HIP_CHECK(hipMemset(vp.p, 0x22, vp.bytes)); HIP_CHECK(hipDeviceSynchronize());
         printf("trial %d (K at %p, V at %p), us per launch by layer:\n ", trial, kp.p, vp.p);
         double sum = 0;
-        for (int l = 0; l < L; ++l) {
+        std::vector<double> us(L);
+        for (int i_ = 0; i_ < L; ++i_) {
+            const int l = order == 0 ? i_ : order == 1 ? L - 1 - i_ : (i_ * 13 + 5) % L;
             for (int rep = 0; rep < 2; ++rep) {  // first round warms up
                 HIP_CHECK(hipEventRecord(e0, s));
                 for (int i = 0; i < 8; ++i)
@@ -30,10 +33,11 @@ int main(int argc, char** argv) {
                 HIP_CHECK(hipEventSynchronize(e1));
             }
             float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-            printf(" %.0f", ms * 1e3 / 8);
+            us[l] = ms * 1e3 / 8;
             sum += ms * 1e3 / 8;
         }
-        printf("\n  mean %.1f us\n", sum / L);
+        for (int l = 0; l < L; ++l) printf(" %.0f", us[l]);
+        printf("\n  mean %.1f us (timed in order %d; listed by layer)\n", sum / L, order);
     }
     return 0;
 }
