@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp2_cu_kernel(const GemmParams p
     for (;;) {
         const int seq = cu_queue_next(cw, key >> 8, v, per_xcd, tiles, &s_tmp);  // ends with a barrier: every wave has left the previous tile's ring
         if (seq < 0) break;
-        pp2_tile(p, seq, 0, reinterpret_cast<half8*>(gemm_smem));
+        pp2_tile<false>(p, seq, 0, reinterpret_cast<half8*>(gemm_smem));
     }
 }
 

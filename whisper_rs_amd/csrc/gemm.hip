@@ -129,6 +129,9 @@ struct GemmParams {
     half_t* vcache;
     int64_t cache_row_stride;
     const StepParams* sp;
+    half_t* pack_k;          // != null: K / V columns go to the packed attention formats (GemmEpi)
+    half_t* pack_v;
+    int pack_T, pack_Tp, pack_H, pack_k_col0, pack_v_col0;
 };
 
 // Two 4-column groups of a lane's row (fp32, columns 16 i + 4 q .. and 16 (i + 1) + 4 q .. with q = lane >> 4) -> fp16, then
@@ -298,6 +301,59 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, floatx4 (&acc
                     else reinterpret_cast<half_t*>(p.c)[crow * p.ldc + nn] = (_Float16)x;
                 }
             }
+        }
+    }
+}
+
+// K columns of one wave's 64-row x 64-column block -> packed K (attention.hip: Kp [Tp/16][2][64 lanes][8], element (kt, ks, l, j) =
+// K[kt*16 + (l & 15)][ks*32 + 8*(l >> 4) + j] per (audio, head)).  After the row exchange a lane owns 8 consecutive dims of one key:
+// exactly one 16-byte entry of the format.  ncolw is a multiple of 64 (one head per call).
+__device__ __forceinline__ void gemm_epilogue_pack_k(const GemmParams& p, floatx4 (&acc)[4][4], const int64_t mrow0, const int ncolw, const int lane) {
+    const int q16 = lane >> 4;
+    const int ncol0 = ncolw + 4 * q16;
+    const int64_t head_halfs = (int64_t)p.pack_Tp * 64;
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        const int na = ncol0 + i * 16, nb = na + 16;
+        const floatx4 ba = p.bias ? *reinterpret_cast<const floatx4*>(p.bias + na) : floatx4{0.f, 0.f, 0.f, 0.f};
+        const floatx4 bb = p.bias ? *reinterpret_cast<const floatx4*>(p.bias + nb) : floatx4{0.f, 0.f, 0.f, 0.f};
+        const float sa = na < p.scale_n_end ? p.scale : 1.f, sb = nb < p.scale_n_end ? p.scale : 1.f;
+        const int nk = ncolw + 16 * (i + (q16 & 1)) + 8 * (q16 >> 1) - p.pack_k_col0;  // this lane's first K column after the exchange
+        const int h = nk >> 6, dd = nk & 63;
+        const int frag = (dd >> 5) * 64 + ((dd & 31) >> 3) * 16;  // (ks, 16-byte chunk) -> lane slot of the fragment
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = (int)mrow0 + j * 16 + (lane & 15);
+            const uint4 w = epi_pair16((acc[i][j] + ba) * sa, (acc[i + 1][j] + bb) * sb);
+            if (m >= p.M) continue;
+            const int b = m / p.pack_T, t = m - b * p.pack_T;
+            *reinterpret_cast<uint4*>(p.pack_k + ((int64_t)b * p.pack_H + h) * head_halfs + ((int64_t)((t >> 4) * 128 + frag + (t & 15)) << 3)) = w;
+        }
+    }
+}
+// V columns, accumulated with the MFMA operands SWAPPED (activation fragment as the A operand): a lane then holds 4 consecutive
+// keys (rows) of one dim (column) — the transposed order of packed V (Vp [Tp/32][4][64 lanes][8], element (kb, dt, l, j) =
+// V[kb*32 + kperm(l >> 4, j)][dt*16 + (l & 15)], kperm(q, j) = j < 4 ? 4q + j : 16 + 4q + (j - 4)): one 8-byte store, no transpose.
+// acc[i][j][r]: column ncolw + 16 i + (lane & 15), row mrow0 + 16 j + 4 (lane >> 4) + r.  pack_T % 4 == 0: a lane's 4 rows never straddle two audios.
+__device__ __forceinline__ void gemm_epilogue_pack_v(const GemmParams& p, floatx4 (&acc)[4][4], const int64_t mrow0, const int ncolw, const int lane) {
+    const int64_t head_halfs = (int64_t)p.pack_Tp * 64;
+    const int d = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = ncolw + 16 * i + d, nv = n - p.pack_v_col0;
+        const int h = nv >> 6, dt = (nv & 63) >> 4;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float sc = n < p.scale_n_end ? p.scale : 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m0 = (int)mrow0 + j * 16 + 4 * (lane >> 4);
+            if (m0 >= p.M) continue;
+            const int b = m0 / p.pack_T, t = m0 - b * p.pack_T;
+            const int pp = t & 31;
+            const floatx4 v = (acc[i][j] + bias) * sc;
+            *reinterpret_cast<half4*>(p.pack_v + ((int64_t)b * p.pack_H + h) * head_halfs +
+                                      ((int64_t)(((t >> 5) * 4 + dt) * 64 + ((pp & 15) >> 2) * 16 + d) << 3) + (pp >> 4) * 4) =
+                half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
         }
     }
 }
@@ -603,6 +659,10 @@ __global__ __launch_bounds__(64 * (NC + NL)) void gemm_f16_ring_kernel(const Gem
 // l>>4 of rows l&15: the chunk position is XOR-swizzled with (row >> 2) & 3 (on the source address of the request, the
 // LDS destination of a direct-to-LDS load being lane-linear) so the 16 lanes of a read group hit 64 distinct banks.
 // one 256x256 tile (number `seq` of the XCD-aware sequence, k-slice `kslice`) by the 8 waves of a workgroup
+// VSWAP: the MFMA operands swapped (D^T per 16x16 block: a lane holds 4 consecutive rows of one column) and the packed-V epilogue
+// (gemm_epilogue_pack_v): the V columns of a K/V projection run as a launch of their own (a runtime switch between the two operand
+// orders in one kernel made the register allocator spill 417 registers).
+template <bool VSWAP>
 __device__ __forceinline__ void pp2_tile(const GemmParams& p, const int seq, const int kslice, half8* smem) {
     constexpr int STAGE = 2048;  // half8 units per ring slot: activations 256 x 64 B (1024) + weights 16 fragments (1024)
     int tid = threadIdx.x;
@@ -671,8 +731,13 @@ __device__ __forceinline__ void pp2_tile(const GemmParams& p, const int seq, con
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc0[i][j], 0, 0, 0);
-                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[4 + i], af[j], acc1[i][j], 0, 0, 0);
+                if (VSWAP) {
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], wf[i], acc0[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], wf[4 + i], acc1[i][j], 0, 0, 0);
+                } else {
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc0[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[4 + i], af[j], acc1[i][j], 0, 0, 0);
+                }
             }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -711,6 +776,16 @@ __device__ __forceinline__ void pp2_tile(const GemmParams& p, const int seq, con
 #undef WRS_PP2_ISSUE
 #undef WRS_PP2_BARRIER
     const int64_t mrow = (int64_t)m0 + grp * 128 + wx * 64;
+    if (VSWAP) {
+        gemm_epilogue_pack_v(p, acc0, mrow, n0 + wy * 128, lane);
+        gemm_epilogue_pack_v(p, acc1, mrow, n0 + wy * 128 + 64, lane);
+        return;
+    }
+    if (p.pack_k != nullptr && n0 >= p.pack_k_col0) {
+        gemm_epilogue_pack_k(p, acc0, mrow, n0 + wy * 128, lane);
+        gemm_epilogue_pack_k(p, acc1, mrow, n0 + wy * 128 + 64, lane);
+        return;
+    }
     gemm_epilogue<4, true>(p, acc0, mrow, n0 + wy * 128, lane);
     gemm_epilogue<4, true>(p, acc1, mrow, n0 + wy * 128 + 64, lane);
 }
@@ -721,7 +796,15 @@ __global__ __launch_bounds__(512) void gemm_f16_pp2_kernel(const GemmParams p) {
     const int tiles = mt_n * nt_n, per_xcd = (tiles + 7) >> 3;
     const int seq = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (seq >= tiles) return;  // whole workgroup, before any barrier
-    pp2_tile(p, seq, blockIdx.y, reinterpret_cast<half8*>(gemm_smem));
+    pp2_tile<false>(p, seq, blockIdx.y, reinterpret_cast<half8*>(gemm_smem));
+}
+__global__ __launch_bounds__(512) void gemm_f16_pp2v_kernel(const GemmParams p) {  // V columns -> packed V (operands swapped)
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+    const int mt_n = (p.M + 255) >> 8, nt_n = p.N >> 8;
+    const int tiles = mt_n * nt_n, per_xcd = (tiles + 7) >> 3;
+    const int seq = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (seq >= tiles) return;
+    pp2_tile<true>(p, seq, blockIdx.y, reinterpret_cast<half8*>(gemm_smem));
 }
 
 static int gemm_pp2_min_wgs = 256;
@@ -731,6 +814,10 @@ static int g_gemm_force = GEMM_AUTO;
 static int g_gemm_last = GEMM_AUTO;
 void gemm_debug_force(int kernel) { g_gemm_force = kernel; }
 int gemm_debug_last() { return g_gemm_last; }
+
+bool gemm_pack_kv_supported(int64_t M, int64_t N) {
+    return N % 256 == 0 && cdiv(M, 256) * (N / 256) >= gemm_pp2_min_wgs;
+}
 
 void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t N, int64_t K, const GemmEpi& e,
                      hipStream_t s) {
@@ -745,6 +832,13 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     p.residual = e.residual; p.posemb = e.posemb; p.c = e.c; p.c_f32 = e.c_f32; p.ldc = e.ldc;
     p.c_rpb = e.c_rows_per_batch; p.c_brows = e.c_batch_rows; p.c_roff = e.c_row_off; p.c_packed = e.c_packed;
     p.qkv_d_model = e.qkv_d_model; p.kcache = e.kcache; p.vcache = e.vcache; p.cache_row_stride = e.cache_row_stride; p.sp = e.sp;
+    p.pack_k = e.pack_k; p.pack_v = e.pack_v; p.pack_T = e.pack_T; p.pack_Tp = (int)round_up(std::max(e.pack_T, 1), 32); p.pack_H = e.pack_H;
+    p.pack_k_col0 = e.pack_k_col0; p.pack_v_col0 = e.pack_v_col0;
+    if (e.pack_k)
+        WRS_REQUIRE(e.pack_v && !A.packed && gemm_pack_kv_supported(M, N) && e.ksplit <= 1 && e.pack_T >= 4 && e.pack_T % 4 == 0 && M % e.pack_T == 0 && e.pack_H >= 1 &&
+                        e.pack_k_col0 % 256 == 0 && e.pack_v_col0 % 256 == 0 && e.pack_k_col0 < e.pack_v_col0 && e.pack_v_col0 < N &&
+                        e.pack_v_col0 - e.pack_k_col0 == (int64_t)e.pack_H * 64 && N - e.pack_v_col0 == (int64_t)e.pack_H * 64 && !e.residual && !e.posemb && !e.act &&
+                        !e.c_f32 && !e.c_packed && e.qkv_d_model == 0 && (e.pack_k_col0 == 0 || e.c), "gemm_f16: bad packed-K/V epilogue");
     if (e.qkv_d_model > 0)
         WRS_REQUIRE(N == 3 * (int64_t)e.qkv_d_model && e.qkv_d_model % 64 == 0 && e.c && !e.c_f32 && !e.c_packed && e.ldc >= e.qkv_d_model && e.ldc % 8 == 0 &&
                         e.kcache && e.vcache && e.sp && e.cache_row_stride >= e.qkv_d_model && e.cache_row_stride % 8 == 0 && e.ksplit <= 1 && !e.residual && !e.posemb && !e.act &&
@@ -763,11 +857,29 @@ void launch_gemm_f16(const GemmA& A, const half_t* w_packed, int64_t M, int64_t 
     const int64_t pp2_tiles = cdiv(M, 256) * (N / 256);
     const bool pp2_ok = !A.packed && N % 256 == 0 && (K / 32) % p.ksplit == 0;
     if (force == GEMM_PP2) WRS_REQUIRE(pp2_ok, "gemm_f16: the 256x256 kernel needs row-major A and N %% 256 == 0");
-    if (pp2_ok && (force == GEMM_PP2 || (force == GEMM_AUTO && (pp2_mode == 2 || (pp2_mode == 1 && pp2_tiles * p.ksplit >= gemm_pp2_min_wgs))))) {
-        const dim3 g((unsigned)(8 * cdiv(pp2_tiles, 8)), (unsigned)p.ksplit);
+    if (pp2_ok && (force == GEMM_PP2 || e.pack_k || (force == GEMM_AUTO && (pp2_mode == 2 || (pp2_mode == 1 && pp2_tiles * p.ksplit >= gemm_pp2_min_wgs))))) {
         const size_t shmem = 4 * 2048 * 16;
         static std::atomic<bool> attr[64];
         allow_dynamic_lds(reinterpret_cast<const void*>(gemm_f16_pp2_kernel), shmem, attr);
+        if (e.pack_k) {
+            // two launches: columns [0, pack_v_col0) on the kernel above (Q, if any, to c; K to packed K), the V columns on the
+            // operand-swapped instantiation (a sub-GEMM of its own: weight rows, bias and scale range shifted by pack_v_col0)
+            static std::atomic<bool> attr_v[64];
+            allow_dynamic_lds(reinterpret_cast<const void*>(gemm_f16_pp2v_kernel), shmem, attr_v);
+            GemmParams pk = p;
+            pk.N = e.pack_v_col0;
+            gemm_f16_pp2_kernel<<<dim3((unsigned)(8 * cdiv(cdiv(M, 256) * (pk.N / 256), 8)), 1), 512, shmem, s>>>(pk);
+            GemmParams pv = p;
+            pv.N = (int)(N - e.pack_v_col0);
+            pv.wp = w_packed + (int64_t)e.pack_v_col0 * K;
+            pv.bias = e.bias ? e.bias + e.pack_v_col0 : nullptr;
+            pv.scale_n_end = std::max(0, e.scale_n_end - e.pack_v_col0);
+            pv.pack_v_col0 = 0;
+            gemm_f16_pp2v_kernel<<<dim3((unsigned)(8 * cdiv(cdiv(M, 256) * (pv.N / 256), 8)), 1), 512, shmem, s>>>(pv);
+            g_gemm_last = GEMM_PP2;
+            return;
+        }
+        const dim3 g((unsigned)(8 * cdiv(pp2_tiles, 8)), (unsigned)p.ksplit);
         gemm_f16_pp2_kernel<<<g, 512, shmem, s>>>(p);
         g_gemm_last = GEMM_PP2;
         return;

@@ -103,7 +103,17 @@ struct GemmEpi {
     half_t* vcache = nullptr;
     int64_t cache_row_stride = 0;          // halfs between physical rows (n_ctx * D)
     const StepParams* sp = nullptr;
+    // K / V projections of the encoder and of the decoder's cross-attention written STRAIGHT into the packed per-(audio, head)
+    // formats of attention.hip (Kp / Vp; row m of the GEMM = key m % pack_T of audio m / pack_T): columns [pack_k_col0,
+    // pack_v_col0) are K, [pack_v_col0, N) are V, columns below pack_k_col0 (the encoder's Q) go to c as usual.  Replaces the
+    // fp16 [M, N] round trip through launch_pack_kv.  256x256 ping-pong kernel only (gemm_pack_kv_supported).
+    half_t* pack_k = nullptr;
+    half_t* pack_v = nullptr;
+    int pack_T = 0, pack_H = 0;
+    int pack_k_col0 = 0, pack_v_col0 = 0;
 };
+// true when launch_gemm_f16 would run (M, N) on the 256x256 ping-pong kernel, the one that has the pack_k / pack_v epilogue
+bool gemm_pack_kv_supported(int64_t M, int64_t N);
 struct GemmA {
     const half_t* a = nullptr;
     int64_t lda = 0;                       // halfs between consecutive rows (may be < K: overlapping rows)

@@ -368,6 +368,7 @@ void Model::encoder_from_mel_t(int n) {
     const float scale = std::pow((float)(D / H), -0.25f);
     const double dM = (double)M, dD = (double)D;
     int dbg_left = debug_enc_stop;  // debug hook: run only the first N launches (0 = all)
+    const bool fused = fused_kv_pack && debug_enc_stop == 0 && D % 256 == 0 && T % 4 == 0 && gemm_pack_kv_supported(M, 3 * (int64_t)D);
 #define WRS_DBG_STEP() do { if (debug_enc_stop > 0 && --dbg_left <= 0) return; } while (0)
     {   // conv1 + GELU (model.rs:421) as implicit GEMM, K = 3*80 (padded to 256 with zero weights)
         Timed tm(timer, "enc_conv1", stream, 0, 2.0 * n * 3000 * 240 * dD);
@@ -399,10 +400,13 @@ void Model::encoder_from_mel_t(int n) {
             GemmA A{w.xn.as<half_t>(), D};
             GemmEpi e;
             e.bias = b.qkv_b; e.scale = scale; e.scale_n_end = 2 * D; e.c = w.qkv.p; e.ldc = 3 * D;
+            if (fused) {  // q -> qkv buffer as before; k, v -> packed K / V from the epilogue
+                e.pack_k = w.kp.as<half_t>(); e.pack_v = w.vp.as<half_t>(); e.pack_T = T; e.pack_H = H; e.pack_k_col0 = D; e.pack_v_col0 = 2 * D;
+            }
             launch_gemm_f16(A, b.qkv_w, M, 3 * D, D, e, stream);
         }
         WRS_DBG_STEP();
-        {
+        if (!fused) {
             Timed tm(timer, "enc_pack_kv", stream, dM * dD * 2 * 2 * 2);
             launch_pack_kv(w.qkv.as<half_t>(), 3 * D, D, 2 * D, n, T, H, w.kp.as<half_t>(), w.vp.as<half_t>(), stream);
         }
@@ -455,6 +459,7 @@ void Model::read_switches() {
     if (const char* e = exp_env("WRS_DEC_BIG_GEMM_ROWS")) dec_big_gemm_rows = atoi(e);
     const char* e = exp_env("WRS_DEC_PRING");
     dec_slab_path = !(e && e[0] == '1');
+    if (const char* f = exp_env("WRS_FUSED_PACK")) fused_kv_pack = f[0] == '1';
     e = exp_env("WRS_DEC_FUSED");
     dec_fused_tiny = e && e[0] == '1';
     e = exp_env("WRS_SELF_MFMA_MIN_AUDIO");
@@ -503,6 +508,7 @@ void Model::load_cross_kv(DecState& st, const half_t* xa16, int n_audio) {
     const int64_t M = (int64_t)n_audio * T;
     const float scale = std::pow((float)(D / H), -0.25f);
     const size_t per_layer = (size_t)st.a_cap * H * packed_kv_halfs_per_head(T);
+    const bool fused = fused_kv_pack && D % 256 == 0 && T % 4 == 0 && gemm_pack_kv_supported(M, 2 * (int64_t)D);
     for (int l = 0; l < L_dec; ++l) {
         const BlockW& b = dec[l];
         {
@@ -510,9 +516,13 @@ void Model::load_cross_kv(DecState& st, const half_t* xa16, int n_audio) {
             GemmA A{xa16, D};
             GemmEpi e;
             e.bias = b.ckv_b; e.scale = scale; e.scale_n_end = D; e.c = st.ckv_tmp.p; e.ldc = 2 * D;
+            if (fused) {
+                e.pack_k = st.ckp(st.cross_wsel) + l * per_layer; e.pack_v = st.cvp(st.cross_wsel) + l * per_layer;
+                e.pack_T = T; e.pack_H = H; e.pack_k_col0 = 0; e.pack_v_col0 = D;
+            }
             launch_gemm_f16(A, b.ckv_w, M, 2 * D, D, e, stream);
         }
-        {
+        if (!fused) {
             Timed tm(timer, "dec_cross_kv_pack", stream, (double)M * D * 2 * 2 * 2);
             launch_pack_kv(st.ckv_tmp.as<half_t>(), 2 * D, 0, D, n_audio, T, H, st.ckp(st.cross_wsel) + l * per_layer,
                            st.cvp(st.cross_wsel) + l * per_layer, stream);

@@ -155,6 +155,7 @@ struct Model {
     int dec_big_gemm_rows = 480;            // decode steps with at least this many rows use the tiled GEMM (env WRS_DEC_BIG_GEMM_ROWS)
     bool dec_fused_tiny = false;            // <= 16 rows, WRS_DEC_FUSED=1: finish kernels fused into the next GEMM's prologue (8 launches per layer instead of 12, but slower: DESIGN.md section 4)
     int self_mfma_min_audio = 64;           // beam-de-duplicating MFMA self-attention from this many audios per step (WRS_SELF_MFMA_MIN_AUDIO; 0 = never)
+    bool fused_kv_pack = true;              // K / V projections written straight into the packed attention formats by the GEMM epilogue (test build: WRS_FUSED_PACK=0 restores launch_pack_kv)
     bool dec_slab_path = true;              // split-K fp32 slabs + finish kernels; WRS_DEC_PRING=1 selects the persistent-ring form (slower, see model.cpp)
     int step_paths_seen = 0;                // diagnosis: OR of the forms decoder_step has taken on this model (1 tiled GEMMs, 2 persistent ring, 4 fused prologue, 8 MFMA self-attention, 16 QKV hand-over)
     void read_switches();                   // experiment switches from the environment, ONCE per model (wrs_model_create)
