@@ -74,6 +74,13 @@ typedef struct wrs_debug_gemm {
     void* vcache;
     int32_t n_ctx, cache_pos, phys_mul;
     int32_t pring_workgroups; /* out */
+    /* path TILED with pack_k != NULL: the K / V projection epilogue of the 256x256 kernel — columns [pack_k_col0, pack_v_col0) go to
+     * pack_k and [pack_v_col0, N) to pack_v in the packed per-(audio, head) attention formats (csrc/attention.hip header; row m = key
+     * m % pack_T of audio m / pack_T; buffers of (M / pack_T) * pack_H * round_up(pack_T, 32) * 64 halfs, zero-filled by the caller),
+     * columns below pack_k_col0 to c (fp16 [M, ldc]) */
+    void* pack_k;
+    void* pack_v;
+    int32_t pack_T, pack_H, pack_k_col0, pack_v_col0;
 } wrs_debug_gemm;
 int wrs_debug_gemm_f16(wrs_debug_gemm* g);
 

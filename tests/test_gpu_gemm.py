@@ -439,3 +439,62 @@ def test_tiled_qkv_epilogue_writes_cache(gpu, M, cache_pos):
     keep = torch.ones(n_ctx, dtype=torch.bool, device=dev)
     keep[cache_pos] = False
     assert torch.equal(kc[:, keep], kc0[:, keep]) and torch.equal(vc[:, keep], vc0[:, keep]), "a cache position other than the step's was written"
+
+
+def _pack_k_ref(k, n_audio, T, H):
+    """packed K of csrc/attention.hip: Kp [audio][head][Tp/16][2][64 lanes][8], (kt, ks, l, j) = K[kt*16 + (l & 15)][ks*32 + 8*(l >> 4) + j]."""
+    Tp = -(-T // 32) * 32
+    kk = torch.zeros(n_audio, Tp, H, 64, dtype=k.dtype, device=k.device)
+    kk[:, :T] = k.view(n_audio, T, H, 64)
+    kk = kk.permute(0, 2, 1, 3).reshape(n_audio, H, Tp // 16, 16, 2, 4, 8)        # [a, h, kt, key, ks, chunk, j]
+    return kk.permute(0, 1, 2, 4, 5, 3, 6).reshape(n_audio, H, Tp // 16, 2, 64, 8)  # lane = chunk*16 + key
+
+
+def _pack_v_ref(v, n_audio, T, H):
+    """packed V: Vp [audio][head][Tp/32][4][64 lanes][8], (kb, dt, l, j) = V[kb*32 + kperm(l >> 4, j)][dt*16 + (l & 15)],
+    kperm(q, j) = j < 4 ? 4q + j : 16 + 4q + (j - 4)."""
+    Tp = -(-T // 32) * 32
+    vv = torch.zeros(n_audio, Tp, H, 64, dtype=v.dtype, device=v.device)
+    vv[:, :T] = v.view(n_audio, T, H, 64)
+    vv = vv.permute(0, 2, 1, 3).reshape(n_audio, H, Tp // 32, 2, 4, 4, 4, 16)      # [a, h, kb, half, q, r, dt, d]: key = 16*half + 4*q + r
+    return vv.permute(0, 1, 2, 6, 4, 7, 3, 5).reshape(n_audio, H, Tp // 32, 4, 64, 8)  # lane = q*16 + d, j = 4*half + r
+
+
+@pytest.mark.parametrize("with_q", [False, True], ids=["cross_kv", "encoder_qkv"])
+def test_kv_projection_packed_by_the_epilogue(gpu, with_q):
+    """K / V projections of the encoder (N = 3D: q stays row-major) and of the decoder's cross-attention (N = 2D) at large-v2 width:
+    the 256x256 kernel writes K through its 16-byte exchanged stores and V on the operand-swapped instantiation straight into the
+    packed per-(audio, head) formats the attention kernels read.  Checked against torch fp32 matmul packed by an independent
+    restatement of the formats (csrc/attention.hip header); 8 audios x 1500 keys: 16-row tiles straddle audios, the last tile is partial."""
+    n_audio, T, H = 8, 1500, 20
+    M, K = n_audio * T, D
+    N = (3 if with_q else 2) * D
+    k0 = D if with_q else 0
+    a = _rand((M, K), 201)
+    w = _rand((N, K), 202, K ** -0.5).float()
+    bias = _rand((N,), 203, 0.1).float()
+    scale = 64 ** -0.25
+    dev = _dev()
+    Tp = -(-T // 32) * 32
+    kp = torch.zeros(n_audio * H * Tp * 64, dtype=torch.float16, device=dev)
+    vp = torch.zeros_like(kp)
+    q = torch.zeros(M, N, dtype=torch.float16, device=dev)
+    g = DBG.DebugGemmC()
+    g.device_id, g.path, g.force_kernel = 0, DBG.PATH_TILED, DBG.GEMM_AUTO
+    g.M, g.N, g.K = M, N, K
+    g.a, g.a_packed, g.lda = a.data_ptr(), 0, K
+    g.w, g.n_w, g.k_w = w.data_ptr(), N, K
+    g.bias, g.scale, g.scale_n_end = bias.data_ptr(), scale, k0 + D   # q and k are scaled, v is not (model.rs:169-172)
+    g.c, g.c_f32, g.c_packed, g.ldc, g.ksplit = q.data_ptr(), 0, 0, N, 1
+    g.pack_k, g.pack_v, g.pack_T, g.pack_H, g.pack_k_col0, g.pack_v_col0 = kp.data_ptr(), vp.data_ptr(), T, H, k0, k0 + D
+    used = _run(g)
+    assert used == DBG.GEMM_PP2
+    ref = a.float() @ w.t() + bias
+    ref[:, :k0 + D] *= scale
+    kref = _pack_k_ref(ref[:, k0:k0 + D].contiguous(), n_audio, T, H)
+    vref = _pack_v_ref(ref[:, k0 + D:].contiguous(), n_audio, T, H)
+    assert _rel_err(kp.view_as(kref).float(), kref) < TOL_F16
+    assert _rel_err(vp.view_as(vref).float(), vref) < TOL_F16
+    if with_q:
+        assert _rel_err(q[:, :D].float(), ref[:, :D]) < TOL_F16
+        assert not q[:, D:].any(), "the K / V columns must not be written to the row-major buffer any more"

@@ -74,6 +74,10 @@ int wrs_debug_gemm_f16(wrs_debug_gemm* g) {
                 e.kcache = reinterpret_cast<half_t*>(g->kcache); e.vcache = reinterpret_cast<half_t*>(g->vcache);
                 e.cache_row_stride = (int64_t)g->n_ctx * (g->N / 3); e.sp = sp.as<StepParams>();
             }
+            if (g->pack_k) {
+                e.pack_k = reinterpret_cast<half_t*>(g->pack_k); e.pack_v = reinterpret_cast<half_t*>(g->pack_v);
+                e.pack_T = g->pack_T; e.pack_H = g->pack_H; e.pack_k_col0 = g->pack_k_col0; e.pack_v_col0 = g->pack_v_col0;
+            }
             gemm_debug_force(g->force_kernel);
             try {
                 launch_gemm_f16(A, wp.as<half_t>(), g->M, g->N, g->K, e, s);

@@ -25,7 +25,9 @@ class DebugGemmC(C.Structure):
                 ("ldc", C.c_int64), ("c_rows_per_batch", C.c_int64), ("c_batch_rows", C.c_int64), ("c_row_off", C.c_int64),
                 ("ksplit", C.c_int32), ("slab_stride", C.c_int64),
                 ("pring_mode", C.c_int32), ("pring_bm", C.c_int32), ("kcache", C.c_void_p), ("vcache", C.c_void_p),
-                ("n_ctx", C.c_int32), ("cache_pos", C.c_int32), ("phys_mul", C.c_int32), ("pring_workgroups", C.c_int32)]
+                ("n_ctx", C.c_int32), ("cache_pos", C.c_int32), ("phys_mul", C.c_int32), ("pring_workgroups", C.c_int32),
+                ("pack_k", C.c_void_p), ("pack_v", C.c_void_p),
+                ("pack_T", C.c_int32), ("pack_H", C.c_int32), ("pack_k_col0", C.c_int32), ("pack_v_col0", C.c_int32)]
 
 
 class DebugAttnSelfC(C.Structure):
